@@ -1,0 +1,304 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE.  Generates tests/golden/*.npz by IMPORTING THE REFERENCE'S OWN
+MODULES from /root/reference/src (read-only) in the build container — the reference
+cannot travel to the GPU box, its outputs can.
+
+    python oracle/make_goldens.py            # writes tests/golden/*.npz
+
+What runs is the reference's code (CaptioningStudent, LSTMDecoder, AttentionRefinement,
+CaptioningTeacher, DistillationLoss, FeatureProjector, TeacherWrapper,
+create_feature_projectors); the only build-owned pieces are the torch-only stand-ins
+for torchvision/timm (oracle/standins.py), the key-seeded weight generator and the
+synthetic inputs (imagecaptioner_amd/utils/seeded_init.py).  Fixtures hold data only:
+seeds, inputs that cannot be regenerated from a seed, and the reference's outputs.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import standins  # noqa: E402
+from imagecaptioner_amd.utils.seeded_init import apply_seeded_init, synthetic_batch  # noqa: E402
+
+standins.install()
+sys.path.insert(0, "/root/reference/src")
+import student_model as ref_student  # noqa: E402
+import teacher_model as ref_teacher  # noqa: E402
+import distillation_utils as ref_kd  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+V = 5000
+T1 = 16
+
+
+class _Vocab:
+    """Minimal .stoi/.itos object (the only vocabulary API caption_image uses,
+    /root/reference/src/student_model.py:344,372,376)."""
+
+    def __init__(self, n):
+        self.itos = {i: f"w{i}" for i in range(n)}
+        self.itos.update({0: "<PAD>", 1: "<START>", 2: "<END>", 3: "<UNK>"})
+        self.stoi = {w: i for i, w in self.itos.items()}
+
+
+def zero_dropout(m: torch.nn.Module):
+    """p=0 everywhere so that train-mode runs are deterministic."""
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.Dropout):
+            sub.p = 0.0
+        if isinstance(sub, (torch.nn.MultiheadAttention, torch.nn.LSTM)):
+            sub.dropout = 0.0
+    return m
+
+
+def npz(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def top2_margin(logits):
+    t2 = logits.topk(2, dim=-1).values
+    return (t2[..., 0] - t2[..., 1])
+
+
+# ------------------------------------------------------------------ (1) cfg1 student eval + greedy
+def golden_cfg1():
+    torch.manual_seed(0)
+    m = ref_student.CaptioningStudent(V, 128, 256, 1, use_attention_refinement=False)
+    apply_seeded_init(m, seed=0)
+    m.eval()
+    images, caps = synthetic_batch(2, V, T1, seed=1234)
+    with torch.no_grad():
+        logits, enc, hids, attw = m(images, caps[:-1])
+    vocab = _Vocab(V)
+    words = [m.caption_image(images[b], vocab, max_length=20) for b in range(2)]
+    ids = np.full((20, 2), -1, dtype=np.int64)
+    for b, ws in enumerate(words):
+        for t, w in enumerate(ws):
+            ids[t, b] = vocab.stoi[w]
+    npz("cfg1_student_eval.npz", seed=0, batch_seed=1234, logits=logits, argmax=logits.argmax(-1),
+        margin=top2_margin(logits), enc=enc, hid0=hids[0], hid7=hids[7], hid14=hids[14],
+        attw0=attw[0], attw14=attw[14], greedy_ids=ids)
+
+
+# ------------------------------------------------------------------ (2) decoder-only
+def golden_decoders():
+    for (E, H, L) in ((128, 256, 1), (256, 512, 2), (384, 768, 3)):
+        torch.manual_seed(0)
+        Vd = 1000
+        dec = ref_student.LSTMDecoder(Vd, E, H, L, dropout=0.2)
+        apply_seeded_init(dec, seed=3, prefix="decoder.")
+        dec.eval()
+        g = torch.Generator().manual_seed(77)
+        feats = torch.randn(3, 49, E, generator=g)
+        caps = torch.randint(0, Vd, (7, 3), generator=g)
+        feats_g = feats.clone().requires_grad_(True)
+        logits, hids, attw = dec(feats_g, caps)
+        # scalar whose gradient exercises every path incl. hidden states
+        gl = torch.randn(logits.shape, generator=g)
+        gh = torch.randn(len(hids), *hids[0].shape, generator=g)
+        obj = (logits * gl).sum() + (torch.stack(hids) * gh).sum()
+        dec.zero_grad()
+        obj.backward()
+        npz(f"decoder_E{E}_H{H}_L{L}.npz", feats=feats, caps=caps, logits=logits, hids=torch.stack(hids),
+            attw=torch.stack(attw), gl=gl, gh=gh, dfeats=feats_g.grad,
+            d_whh0=dec.lstm.weight_hh_l0.grad[:8], d_wih0=dec.lstm.weight_ih_l0.grad[:8],
+            d_att_w=dec.attention.weight.grad[:8], d_att_b=dec.attention.bias.grad,
+            d_comb_w=dec.attention_combine.weight.grad[:8],
+            d_emb_rows=dec.embedding.weight.grad[caps.flatten()[:6]], emb_row_ids=caps.flatten()[:6],
+            d_out0_w=dec.output_projection[0].weight.grad[:8], d_out3_b=dec.output_projection[3].bias.grad,
+            d_bih_last=getattr(dec.lstm, f"bias_ih_l{L-1}").grad)
+
+
+# ------------------------------------------------------------------ (3) refinement
+def golden_refinement():
+    for E in (256, 384):
+        torch.manual_seed(0)
+        r = ref_student.AttentionRefinement(E)
+        apply_seeded_init(r, seed=4, prefix="attention_refinement.")
+        r.eval()
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(3, 49, E, generator=g)
+        xg = x.clone().requires_grad_(True)
+        y = r(xg)
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy).sum().backward()
+        npz(f"refinement_E{E}.npz", x=x, y=y, gy=gy, dx=xg.grad, d_inproj=r.attention.in_proj_weight.grad[::37],
+            d_inproj_b=r.attention.in_proj_bias.grad, d_outproj=r.attention.out_proj.weight.grad[::29],
+            d_ffn0=r.ffn[0].weight.grad[::41], d_norm1_w=r.norm1.weight.grad, d_norm2_b=r.norm2.bias.grad)
+
+
+# ------------------------------------------------------------------ (4) losses
+def golden_losses():
+    g = torch.Generator().manual_seed(11)
+    T, B, Vl, E, H = 6, 5, 257, 64, 48
+    for tau in (3.0, 4.0):
+        s = (torch.randn(T, B, Vl, generator=g) * 2).requires_grad_(True)
+        t = torch.randn(T, B, Vl, generator=g) * 3
+        tg = torch.randint(1, Vl, (T, B), generator=g)
+        tg[4:, 1] = 0
+        tg[2:, 3] = 0
+        sf = torch.randn(B, 49, E, generator=g).requires_grad_(True)
+        tf = torch.randn(B, 49, E, generator=g).requires_grad_(True)
+        sh = [torch.randn(B, H, generator=g).requires_grad_(True) for _ in range(T)]
+        th = [torch.randn(B, H, generator=g) for _ in range(T - 1)]      # shorter: exercises truncation (:109-113)
+        L = ref_kd.DistillationLoss(alpha=0.5, beta=0.2, gamma=0.1, temperature=tau, vocab_size=Vl)
+        kl = L.token_level_distillation(s, t)
+        fe = L.encoder_feature_distillation(sf, tf)
+        hi = L.decoder_hidden_state_distillation(sh, th)
+        total, parts = L({"logits": s, "encoder_features": sf, "hidden_states": sh},
+                         {"logits": t, "encoder_features": tf, "hidden_states": th}, tg)
+        total.backward()
+        # default weights (CE weight 2.78e-17) and hidden_states None (fact 2)
+        L2 = ref_kd.DistillationLoss(vocab_size=Vl, temperature=tau)
+        total2, parts2 = L2({"logits": s.detach(), "encoder_features": sf.detach(), "hidden_states": sh},
+                            {"logits": t, "encoder_features": tf.detach(), "hidden_states": None}, tg)
+        npz(f"losses_tau{int(tau)}.npz", s=s, t=t, targets=tg, sf=sf, tf=tf, sh=torch.stack(sh), th=torch.stack(th),
+            kl=kl, feat=fe, hid=hi, total=total, ce=parts["ce_loss"], ds=s.grad, dsf=sf.grad, dtf=tf.grad,
+            dsh=torch.stack([x.grad if x.grad is not None else torch.zeros_like(x) for x in sh]), total_default=total2, hid_default=parts2["hidden_kd_loss"],
+            ce_weight_default=(1 - L2.alpha - L2.beta - L2.gamma))
+
+
+# ------------------------------------------------------------------ (5) projector
+def golden_projector():
+    for E in (128, 256, 384):
+        torch.manual_seed(0)
+        pr = ref_kd.FeatureProjector(512, E, 197, 49)
+        apply_seeded_init(pr, seed=2)
+        pr.eval()
+        g = torch.Generator().manual_seed(6)
+        x = torch.randn(2, 197, 512, generator=g)
+        xg = x.clone().requires_grad_(True)
+        y = pr(xg)
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy).sum().backward()
+        npz(f"projector_E{E}.npz", x=x[:, ::8, ::8], x_seed=6, y=y, gy=gy, dx=xg.grad[:, ::8, ::8],
+            dw=pr.feature_projection[0].weight.grad[::16], db=pr.feature_projection[0].bias.grad,
+            dlnw=pr.feature_projection[3].weight.grad)
+    # the reference's own test shape (test_dimension_fix.py:16-43): (2,197,384) -> (2,64,256)
+    pr = ref_kd.FeatureProjector(384, 256, 197, 64)
+    apply_seeded_init(pr, seed=2)
+    pr.eval()
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 197, 384, generator=g)
+    with torch.no_grad():
+        y = pr(x)
+    npz("projector_ref_test_shape.npz", y=y, shape=np.array(y.shape))
+
+
+# ------------------------------------------------------------------ (6) teacher eval
+def build_teacher():
+    torch.manual_seed(0)
+    t = ref_teacher.CaptioningTeacher(V, embed_size=512, num_heads=8, num_decoder_layers=4, dropout=0.15)
+    apply_seeded_init(t, seed=1)
+    t.eval()
+    return t
+
+
+def golden_teacher():
+    t = build_teacher()
+    images, caps = synthetic_batch(2, V, T1, seed=1234)
+    out = ref_kd.TeacherWrapper(t)(images, caps[:-1])
+    with torch.no_grad():
+        vit = t.encoder.forward_features(images)
+    npz("teacher_eval.npz", logits=out["logits"], argmax=out["logits"].argmax(-1), margin=top2_margin(out["logits"]),
+        enc_feats=out["encoder_features"][:, ::4], vit_tokens=vit[:, ::4],
+        hidden_is_none=np.array(out["hidden_states"] is None))
+
+
+# ------------------------------------------------------------------ (7)+(8) train-mode step
+def golden_kd_step():
+    torch.manual_seed(0)
+    t = build_teacher()
+    s = ref_student.CaptioningStudent(V, 256, 512, 2, dropout=0.3, use_attention_refinement=True)
+    apply_seeded_init(s, seed=0)
+    zero_dropout(s)
+    s.train()
+    projectors = ref_kd.create_feature_projectors(t, s)
+    apply_seeded_init(projectors["encoder"], seed=2)
+    zero_dropout(projectors["encoder"])
+    images, caps = synthetic_batch(2, V, T1, seed=1234)
+    cin, ctg = caps[:-1], caps[1:]
+    tw = ref_kd.TeacherWrapper(t)
+    L = ref_kd.DistillationLoss(alpha=0.7, beta=0.2, gamma=0.1, temperature=4.0, vocab_size=V)
+    # optimizer exactly as /root/reference/src/train_student_kd.py:219-236
+    lr = 2e-4
+    other = list(s.attention_refinement.parameters())
+    for pr in projectors.values():
+        other.extend(list(pr.parameters()))
+    opt = torch.optim.AdamW([{"params": list(s.encoder.parameters()), "lr": lr * 0.1},
+                             {"params": list(s.decoder.parameters()), "lr": lr},
+                             {"params": other, "lr": lr}], weight_decay=0.01)
+    t_out = tw(images, cin)
+    logits, enc, hids, attw = s(images, cin)
+    s_out = {"logits": logits, "encoder_features": enc, "hidden_states": hids}
+    t_out["encoder_features"] = projectors["encoder"](t_out["encoder_features"])
+    loss, parts = L(s_out, t_out, ctg)
+    loss.backward()
+    sd = dict(s.named_parameters())
+    frozen_none = all(sd[k].grad is None for k in sd if k.startswith("encoder.resnet.5.") or k.startswith("encoder.resnet.4."))
+    grads = {k: p.grad.clone() for k, p in sd.items() if p.grad is not None}
+    gn_student = torch.sqrt(sum((g ** 2).sum() for g in grads.values()))
+    pj = dict(projectors["encoder"].named_parameters())
+    gn_proj = torch.sqrt(sum((p.grad ** 2).sum() for p in pj.values()))
+    rm_after = s.encoder.resnet[1].running_mean.clone()
+    rv_after = s.encoder.resnet[7][2].bn3.running_var.clone()
+    torch.nn.utils.clip_grad_norm_(s.parameters(), max_norm=1.0)
+    for pr in projectors.values():
+        torch.nn.utils.clip_grad_norm_(pr.parameters(), max_norm=1.0)
+    before = {k: sd[k].detach().clone() for k in ("decoder.lstm.weight_hh_l0", "encoder.resnet.7.2.conv3.weight",
+                                                  "encoder.projection.0.weight", "attention_refinement.ffn.0.weight")}
+    pj_before = pj["feature_projection.0.weight"].detach().clone()
+    opt.step()
+    npz("kd_step_cfg3_B2.npz", loss=loss, ce=parts["ce_loss"], kd=parts["token_kd_loss"], feat=parts["feature_kd_loss"],
+        hid=parts["hidden_kd_loss"], logits_slice=logits[:, :, ::50], enc=enc, t_proj=t_out["encoder_features"],
+        hid14=hids[14], frozen_none=np.array(frozen_none), gn_student=gn_student, gn_proj=gn_proj,
+        g_whh0=grads["decoder.lstm.weight_hh_l0"][::64, ::16],
+        g_l4conv3=grads["encoder.resnet.7.2.conv3.weight"][::64, ::16, 0, 0],
+        g_l3conv2=grads["encoder.resnet.6.0.conv2.weight"][::16, ::16],
+        g_l4ds=grads["encoder.resnet.7.0.downsample.0.weight"][::64, ::32, 0, 0],
+        g_l3bn1_w=grads["encoder.resnet.6.0.bn1.weight"], g_l4bn3_b=grads["encoder.resnet.7.2.bn3.bias"],
+        g_encproj=grads["encoder.projection.0.weight"][::16, ::64],
+        g_ref_inproj=grads["attention_refinement.attention.in_proj_weight"][::32, ::16],
+        g_emb_row1=grads["decoder.embedding.weight"][1], g_out3_b=grads["decoder.output_projection.3.bias"][::10],
+        g_att_w=grads["decoder.attention.weight"][::16, ::16],
+        g_proj_w=pj["feature_projection.0.weight"].grad[::16, ::16] if False else np.zeros(1),
+        bn1_running_mean=rm_after, l4_bn3_running_var=rv_after,
+        d_whh0=(sd["decoder.lstm.weight_hh_l0"].detach() - before["decoder.lstm.weight_hh_l0"])[::64, ::16],
+        d_l4conv3=(sd["encoder.resnet.7.2.conv3.weight"].detach() - before["encoder.resnet.7.2.conv3.weight"])[::64, ::16, 0, 0],
+        d_encproj=(sd["encoder.projection.0.weight"].detach() - before["encoder.projection.0.weight"])[::16, ::64],
+        d_ffn0=(sd["attention_refinement.ffn.0.weight"].detach() - before["attention_refinement.ffn.0.weight"])[::16, ::16],
+        d_projw=(pj["feature_projection.0.weight"].detach() - pj_before)[::16, ::16])
+
+
+def golden_param_counts():
+    """SURVEY.md §0 fact 10 — pins the architecture sizes."""
+    torch.manual_seed(0)
+    s = ref_student.CaptioningStudent(3000)
+    tot, tr = ref_student.count_parameters(s)
+    t = ref_teacher.CaptioningTeacher(3000, embed_size=512, num_heads=8, num_decoder_layers=4, dropout=0.15)
+    tt = sum(p.numel() for p in t.parameters())
+    keys = sorted(s.state_dict().keys())
+    tkeys = sorted(t.state_dict().keys())
+    npz("param_counts.npz", student_total=tot, student_trainable=tr, teacher_total=tt,
+        student_keys=np.array(keys), teacher_keys=np.array(tkeys),
+        student_shapes=np.array([str(tuple(s.state_dict()[k].shape)) for k in keys]),
+        teacher_shapes=np.array([str(tuple(t.state_dict()[k].shape)) for k in tkeys]))
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step"]
+    fns = {"counts": golden_param_counts, "losses": golden_losses, "projector": golden_projector,
+           "refinement": golden_refinement, "decoders": golden_decoders, "cfg1": golden_cfg1,
+           "teacher": golden_teacher, "kd_step": golden_kd_step}
+    for w in which:
+        fns[w]()

@@ -1,0 +1,201 @@
+"""Pins the oracle (oracle/restatement.py) against golden vectors captured from the
+reference's own modules (oracle/make_goldens.py).  CPU only; no GPU needed."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t
+from imagecaptioner_amd.utils.seeded_init import seeded_state_dict, synthetic_batch
+from oracle import restatement as R
+
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL, name=""):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(np.asarray(b)).double()
+    assert a.shape == b.shape, f"{name}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, f"{name}: max abs err {err:.3e} (scale {scale:.3e})"
+
+
+def leafs(sd, grad_filter=lambda k: True):
+    return {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and grad_filter(k)) else v.clone())
+            for k, v in sd.items()}
+
+
+def test_param_counts_and_keys():
+    g = load_golden("param_counts.npz")
+    shapes = R.student_state_shapes(3000, 256, 512, 2, True)
+    gk = [k for k in g["student_keys"].tolist() if not k.endswith("num_batches_tracked")]
+    assert sorted(shapes) == sorted(gk)
+    gs = dict(zip(g["student_keys"].tolist(), g["student_shapes"].tolist()))
+    for k, s in shapes.items():
+        assert str(tuple(s)) == gs[k], k
+    n = sum(int(np.prod(s)) for k, s in shapes.items() if "running_" not in k)
+    assert n == int(g["student_total"]) == 30236920
+    tshapes = R.teacher_state_shapes(3000, 512, 4)
+    tk = [k for k in g["teacher_keys"].tolist() if k != "pos_encoder.pe"]
+    assert sorted(tshapes) == sorted(tk)
+    assert sum(int(np.prod(s)) for s in tshapes.values()) == int(g["teacher_total"]) == 37556536
+
+
+@pytest.mark.parametrize("tau", [3, 4])
+def test_losses(tau):
+    g = load_golden(f"losses_tau{tau}.npz")
+    s = t(g["s"]).requires_grad_(True)
+    sf = t(g["sf"]).requires_grad_(True)
+    tf = t(g["tf"]).requires_grad_(True)
+    sh = [x.clone().requires_grad_(True) for x in t(g["sh"])]
+    th = list(t(g["th"]))
+    close(R.token_kd(s, t(g["t"]), float(tau)), g["kl"], name="kl")
+    close(R.feature_kd(sf, tf), g["feat"], name="feat")
+    close(R.hidden_kd(sh, th), g["hid"], name="hid")
+    total, parts = R.distillation_loss({"logits": s, "encoder_features": sf, "hidden_states": sh},
+                                       {"logits": t(g["t"]), "encoder_features": tf, "hidden_states": th},
+                                       t(g["targets"]), alpha=0.5, beta=0.2, gamma=0.1, tau=float(tau))
+    close(total, g["total"], name="total")
+    assert abs(parts["ce_loss"] - float(g["ce"])) < 1e-5
+    total.backward()
+    close(s.grad, g["ds"], 1e-6, "ds")
+    close(sf.grad, g["dsf"], 1e-6, "dsf")
+    close(tf.grad, g["dtf"], 1e-6, "dtf")
+    close(torch.stack([x.grad if x.grad is not None else torch.zeros_like(x) for x in sh]), g["dsh"], 1e-6, "dsh")
+    # defaults: hidden None -> 0 (fact 2), CE weight 2.78e-17 (fact 3)
+    total2, parts2 = R.distillation_loss({"logits": s.detach(), "encoder_features": sf.detach(), "hidden_states": sh},
+                                         {"logits": t(g["t"]), "encoder_features": tf.detach(), "hidden_states": None},
+                                         t(g["targets"]), tau=float(tau))
+    close(total2, g["total_default"], name="total_default")
+    assert parts2["hidden_kd_loss"] == 0.0 == float(g["hid_default"])
+    assert abs(float(g["ce_weight_default"]) - 2.7755575615628914e-17) < 1e-30
+
+
+def test_loss_errors():
+    with pytest.raises(ValueError):
+        R.feature_kd(torch.zeros(2, 49, 8), torch.zeros(2, 49, 9))
+    with pytest.raises(ValueError):
+        R.hidden_kd([torch.zeros(2, 8)], [torch.zeros(2, 9)])
+
+
+@pytest.mark.parametrize("E", [128, 256, 384])
+def test_projector(E):
+    g = load_golden(f"projector_E{E}.npz")
+    sd = leafs(seeded_state_dict(R.projector_state_shapes(512, E), seed=2))
+    x = torch.randn(2, 197, 512, generator=torch.Generator().manual_seed(int(g["x_seed"]))).requires_grad_(True)
+    close(x.detach()[:, ::8, ::8], g["x"], 0, "x regenerated")
+    y = R.feature_projector(sd, x, 49)
+    close(y, g["y"], name="y")
+    (y * t(g["gy"])).sum().backward()
+    close(x.grad[:, ::8, ::8], g["dx"], name="dx")
+    close(sd["feature_projection.0.weight"].grad[::16], g["dw"], name="dw")
+    close(sd["feature_projection.0.bias"].grad, g["db"], name="db")
+    close(sd["feature_projection.3.weight"].grad, g["dlnw"], name="dlnw")
+
+
+def test_projector_reference_test_shape():
+    """the one shape fact the reference's own test script holds (test_dimension_fix.py:16-43)"""
+    g = load_golden("projector_ref_test_shape.npz")
+    sd = seeded_state_dict(R.projector_state_shapes(384, 256), seed=2)
+    x = torch.randn(2, 197, 384, generator=torch.Generator().manual_seed(6))
+    y = R.feature_projector(sd, x, 64)
+    assert tuple(y.shape) == (2, 64, 256) == tuple(g["shape"])
+    close(y, g["y"], name="y")
+
+
+@pytest.mark.parametrize("E", [256, 384])
+def test_refinement(E):
+    g = load_golden(f"refinement_E{E}.npz")
+    shapes = {k: v for k, v in R.student_state_shapes(10, E, 8, 1, True).items() if k.startswith("attention_refinement")}
+    sd = leafs(seeded_state_dict(shapes, seed=4))
+    x = t(g["x"]).requires_grad_(True)
+    y = R.attention_refinement(sd, x)
+    close(y, g["y"], name="y")
+    (y * t(g["gy"])).sum().backward()
+    close(x.grad, g["dx"], name="dx")
+    close(sd["attention_refinement.attention.in_proj_weight"].grad[::37], g["d_inproj"], name="d_inproj")
+    close(sd["attention_refinement.attention.in_proj_bias"].grad, g["d_inproj_b"], name="d_inproj_b")
+    close(sd["attention_refinement.attention.out_proj.weight"].grad[::29], g["d_outproj"], name="d_outproj")
+    close(sd["attention_refinement.ffn.0.weight"].grad[::41], g["d_ffn0"], name="d_ffn0")
+    close(sd["attention_refinement.norm1.weight"].grad, g["d_norm1_w"], name="d_norm1_w")
+    close(sd["attention_refinement.norm2.bias"].grad, g["d_norm2_b"], name="d_norm2_b")
+
+
+@pytest.mark.parametrize("E,H,L", [(128, 256, 1), (256, 512, 2), (384, 768, 3)])
+def test_decoder(E, H, L):
+    g = load_golden(f"decoder_E{E}_H{H}_L{L}.npz")
+    shapes = {k: v for k, v in R.student_state_shapes(1000, E, H, L, False).items() if k.startswith("decoder.")}
+    sd = leafs(seeded_state_dict(shapes, seed=3))
+    feats = t(g["feats"]).requires_grad_(True)
+    caps = t(g["caps"])
+    logits, hids, attw = R.lstm_decoder(sd, feats, caps, L, H)
+    close(logits, g["logits"], name="logits")
+    close(torch.stack(hids), g["hids"], name="hids")
+    close(torch.stack(attw), g["attw"], name="attw")
+    ((logits * t(g["gl"])).sum() + (torch.stack(hids) * t(g["gh"])).sum()).backward()
+    close(feats.grad, g["dfeats"], name="dfeats")
+    close(sd["decoder.lstm.weight_hh_l0"].grad[:8], g["d_whh0"], name="d_whh0")
+    close(sd["decoder.lstm.weight_ih_l0"].grad[:8], g["d_wih0"], name="d_wih0")
+    close(sd["decoder.attention.weight"].grad[:8], g["d_att_w"], name="d_att_w")
+    close(sd["decoder.attention.bias"].grad, g["d_att_b"], name="d_att_b")
+    close(sd["decoder.attention_combine.weight"].grad[:8], g["d_comb_w"], name="d_comb_w")
+    close(sd["decoder.embedding.weight"].grad[t(g["emb_row_ids"])], g["d_emb_rows"], name="d_emb")
+    close(sd["decoder.output_projection.0.weight"].grad[:8], g["d_out0_w"], name="d_out0_w")
+    close(sd["decoder.output_projection.3.bias"].grad, g["d_out3_b"], name="d_out3_b")
+    close(sd[f"decoder.lstm.bias_ih_l{L - 1}"].grad, g["d_bih_last"], name="d_bih_last")
+
+
+def test_cfg1_student_eval_and_greedy():
+    g = load_golden("cfg1_student_eval.npz")
+    sd = seeded_state_dict(R.student_state_shapes(5000, 128, 256, 1, False), seed=0)
+    images, caps = synthetic_batch(2, 5000, 16, seed=1234)
+    with torch.no_grad():
+        logits, enc, hids, attw = R.student_forward(sd, images, caps[:-1], hidden=256, layers=1, refine=False)
+    close(logits, g["logits"], 1e-4, "logits")
+    close(enc, g["enc"], 1e-4, "enc")
+    close(hids[0], g["hid0"], 1e-4, "hid0")
+    close(hids[14], g["hid14"], 1e-4, "hid14")
+    close(attw[14], g["attw14"], 1e-4, "attw14")
+    assert float(g["margin"].min()) > 1e-3, "golden argmax margins too small to demand bit-exact ids"
+    assert torch.equal(logits.argmax(-1), t(g["argmax"]))
+    ids, _ = R.greedy_decode(sd, images, hidden=256, layers=1, refine=False, max_length=20)
+    assert torch.equal(ids, t(g["greedy_ids"])), (ids.T, g["greedy_ids"].T)
+
+
+def test_teacher_eval():
+    g = load_golden("teacher_eval.npz")
+    sd = seeded_state_dict(R.teacher_state_shapes(5000, 512, 4), seed=1)
+    images, caps = synthetic_batch(2, 5000, 16, seed=1234)
+    logits, feats = R.teacher_forward(sd, images, caps[:-1], heads=8, layers=4)
+    close(logits, g["logits"], 1e-4, "logits")
+    close(feats[:, ::4], g["enc_feats"], 1e-4, "enc_feats")
+    assert bool(g["hidden_is_none"])
+    assert float(g["margin"].min()) > 1e-3
+    assert torch.equal(logits.argmax(-1), t(g["argmax"]))
+
+
+def test_kd_step_train_mode():
+    g = load_golden("kd_step_cfg3_B2.npz")
+    trainable = lambda k: not any(k.startswith(f"encoder.resnet.{i}.") for i in (0, 1, 4, 5)) and "running_" not in k
+    ssd = leafs(seeded_state_dict(R.student_state_shapes(5000, 256, 512, 2, True), seed=0), trainable)
+    tsd = seeded_state_dict(R.teacher_state_shapes(5000, 512, 4), seed=1)
+    psd = leafs(seeded_state_dict(R.projector_state_shapes(512, 256), seed=2))
+    images, caps = synthetic_batch(2, 5000, 16, seed=1234)
+    loss, parts, logits = R.kd_forward_backward(ssd, tsd, psd, images, caps, hidden=512, layers=2, refine=True,
+                                                t_heads=8, t_layers=4)
+    close(loss, g["loss"], 1e-4, "loss")
+    for k, gk in (("ce_loss", "ce"), ("token_kd_loss", "kd"), ("feature_kd_loss", "feat"), ("hidden_kd_loss", "hid")):
+        assert abs(parts[k] - float(g[gk])) <= 1e-4 * max(1.0, abs(float(g[gk]))), k
+    close(logits[:, :, ::50], g["logits_slice"], 1e-4, "logits")
+    assert bool(g["frozen_none"])
+    assert ssd["encoder.resnet.5.0.conv1.weight"].grad is None
+    gn = torch.sqrt(sum((v.grad ** 2).sum() for v in ssd.values() if v.grad is not None))
+    close(gn, g["gn_student"], 1e-3, "gn_student")
+    close(ssd["decoder.lstm.weight_hh_l0"].grad[::64, ::16], g["g_whh0"], 1e-4, "g_whh0")
+    close(ssd["encoder.resnet.7.2.conv3.weight"].grad[::64, ::16, 0, 0], g["g_l4conv3"], 1e-4, "g_l4conv3")
+    close(ssd["encoder.resnet.6.0.conv2.weight"].grad[::16, ::16], g["g_l3conv2"], 1e-4, "g_l3conv2")
+    close(ssd["encoder.resnet.6.0.bn1.weight"].grad, g["g_l3bn1_w"], 1e-4, "g_l3bn1_w")
+    close(ssd["decoder.embedding.weight"].grad[1], g["g_emb_row1"], 1e-4, "g_emb_row1")
+    # BN running stats were updated in train mode, frozen stem included (fact 6)
+    close(ssd["encoder.resnet.1.running_mean"], g["bn1_running_mean"], 1e-4, "bn1 running_mean")
+    close(ssd["encoder.resnet.7.2.bn3.running_var"], g["l4_bn3_running_var"], 1e-4, "l4 bn3 running_var")
