@@ -1,0 +1,402 @@
+// igemm_f32.hip — fp32 implicit-GEMM family on the CDNA4 matrix cores (gfx950).
+//
+//   C[z][m][n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) + residual[m][n]
+//
+// One LDS-tiled kernel template built on v_mfma_f32_32x32x2_f32 (exact fp32: the result is
+// a k-ordered fmaf chain, so parity with the reference's fp32 CPU path holds to ~1e-6) serves
+// every dense contraction of the KD step: Linear fwd/bwd, batched attention products, and the
+// ResNet-50 convolutions (fwd / dgrad / wgrad) as implicit GEMM over NHWC activations.
+//
+// Tiling (64-wide wavefronts): 256 threads = 4 waves in a 2x2 grid; block tile BMxBNx16;
+// each wave owns (BM/2)x(BN/2) = TMxTN MFMA tiles of 32x32 (16 accumulator VGPRs each).
+// Operand tiles live in LDS k-major, As[k][m] / Bs[k][n], so the MFMA fragment read
+// (lane l: A[m = l&31][k = l>>5]) is one conflict-free ds_read_b32 per tile per k-pair.
+//   * a source that is contiguous along K (row-major activations, conv im2col over NHWC
+//     channels, [N][K] weights) is fetched as float4 along k and TRANSPOSED on the LDS write
+//     (4 x ds_write_b32; row pitch = BX+2 makes the 32-lane write group conflict-free);
+//   * a source that is contiguous along M/N ([K][N] weights for dgrad, dY^T for wgrad) is
+//     fetched as float4 along x and stored with one ds_write_b128 (row pitch BX+4).
+// Global->LDS is software pipelined through registers (issue tile t+1's loads, run tile t's
+// MFMAs, then write t+1 into the other LDS buffer): one barrier per k-tile.
+#include "ick_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+constexpr int NT = 256;
+
+struct P {  // kernel parameters (by value)
+  const float* A; const float* B; float* C;
+  const float* bias; const float* residual; float* stat_sum; float* stat_sq;
+  int M, N, K;
+  long lda, ldb, ldc, ldr;
+  int batch_inner;
+  long sAo, sAi, sBo, sBi, sCo, sCi;
+  int splitk, kps, accumulate, act;
+  float alpha;
+  int Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+};
+
+// which fetch pattern each op uses for its A and B operands
+__host__ __device__ constexpr bool a_kcontig(int op) { return op != ICK_OP_TN && op != ICK_OP_CONV_WGRAD; }
+__host__ __device__ constexpr bool b_kcontig(int op) {
+  return op == ICK_OP_NT || op == ICK_OP_CONV_FWD || op == ICK_OP_CONV_FWD_C4;
+}
+
+__device__ __forceinline__ float4 ldg4(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+// k-contiguous fetch of elements [k, k+4) of a row whose valid range ends at kend (any kend: the row pitch is a
+// multiple of 4, so the 16-byte load stays inside the row; components past kend are zeroed)
+__device__ __forceinline__ float4 ldg4k(const float* p, bool ok, int k, int kend) {
+  float4 v = ldg4(p, ok && k < kend);
+  if (k + 3 >= kend) {
+    if (k + 1 >= kend) v.y = 0.f;
+    if (k + 2 >= kend) v.z = 0.f;
+    v.w = 0.f;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+  if (act == ICK_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ICK_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  if (act == ICK_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+template <int OP, int BM, int BN>
+__global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
+  constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
+  constexpr int BMP = BM + (AK ? 2 : 4), BNP = BN + (BKc ? 2 : 4);
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  // k-contiguous fetch: 4 threads per row, 64 rows per pass; x-contiguous: BX/4 threads per k-row
+  constexpr int PA = AK ? BM / 64 : (BK * BM) / 1024;
+  constexpr int PB = BKc ? BN / 64 : (BK * BN) / 1024;
+  constexpr int A_TPK = BM / 4, B_TPK = BN / 4;        // threads per k-row (x-contiguous)
+  constexpr int A_KR = NT / A_TPK, B_KR = NT / B_TPK;  // k-rows per pass   (x-contiguous)
+
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BMP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BNP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+  // batch / split-K decomposition of blockIdx.z
+  int z = blockIdx.z, split = 0;
+  if (p.splitk > 1) { split = z; z = 0; }
+  const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
+  const float* __restrict__ Ag = p.A + zo * p.sAo + zi * p.sAi;
+  const float* __restrict__ Bg = p.B + zo * p.sBo + zi * p.sBi;
+  const long coff = zo * p.sCo + zi * p.sCi;
+  const int kbeg = split * p.kps;
+  const int kend = min(p.K, kbeg + p.kps);
+  const int nkt = (kend - kbeg + BK - 1) / BK;
+
+  // ---------------------------------------------------------------- per-thread fetch state
+  // A side
+  const float* a_ptr[PA]; bool a_ok[PA]; int a_y[PA], a_x[PA];
+  const int a_k4 = (tid & 3) * 4;  // k offset inside the tile (k-contiguous fetch)
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    if constexpr (AK) {
+      const int m = m0 + i * 64 + (tid >> 2);
+      a_ok[i] = m < p.M;
+      if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
+        a_ptr[i] = Ag + (long)m * p.lda + a_k4; a_y[i] = a_x[i] = 0;
+      } else if constexpr (OP == ICK_OP_CONV_FWD || OP == ICK_OP_CONV_FWD_C4) {
+        const int hw = p.Ho * p.Wo; const int b = m / hw; const int r = m - b * hw;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad;
+        a_ptr[i] = Ag + (long)b * p.H * p.W * p.Cin;
+      } else {  // CONV_DGRAD: rows are input pixels, gather from dY
+        const int hw = p.H * p.W; const int b = m / hw; const int r = m - b * hw;
+        const int iy = r / p.W, ix = r - iy * p.W;
+        a_y[i] = iy + p.pad; a_x[i] = ix + p.pad;
+        a_ptr[i] = Ag + (long)b * p.Ho * p.Wo * p.Cout;
+      }
+    } else {  // x-contiguous: A stored [K][M]
+      const int m = m0 + (tid % A_TPK) * 4;
+      a_ok[i] = m < p.M;
+      a_ptr[i] = Ag + m; a_y[i] = i * A_KR + tid / A_TPK; a_x[i] = 0;
+    }
+  }
+  // B side
+  const float* b_ptr[PB]; bool b_ok[PB]; int b_y[PB], b_x[PB];
+  int b_r = 0, b_s = 0;
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    if constexpr (BKc) {
+      const int n = n0 + i * 64 + (tid >> 2);
+      b_ok[i] = n < p.N;
+      b_ptr[i] = Bg + (long)n * p.ldb + a_k4; b_y[i] = b_x[i] = 0;
+    } else {
+      const int n = n0 + (tid % B_TPK) * 4;
+      b_ok[i] = n < p.N;
+      b_y[i] = i * B_KR + tid / B_TPK; b_x[i] = 0;
+      if constexpr (OP == ICK_OP_CONV_WGRAD) {
+        const int tap = n / p.Cin; const int ci = n - tap * p.Cin;
+        b_r = tap / p.S; b_s = tap - b_r * p.S;
+        b_ptr[i] = Bg + ci;
+      } else {
+        b_ptr[i] = Bg + n;
+      }
+    }
+  }
+
+  float4 ra[PA], rb[PB];
+
+  auto fetch = [&](int kt) {
+    const int k0 = kbeg + kt * BK;
+    // ---- A
+    if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i) ra[i] = ldg4k(a_ptr[i] + k0, a_ok[i], k0 + a_k4, kend);
+    } else if constexpr (OP == ICK_OP_CONV_FWD) {
+      const int tap = k0 / p.Cin; const int ci = k0 - tap * p.Cin + a_k4;
+      const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int iy = a_y[i] + r, ix = a_x[i] + s;
+        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (k0 + a_k4 < kend);
+        ra[i] = ldg4(a_ptr[i] + ((long)iy * p.W + ix) * p.Cin + ci, ok);
+      }
+    } else if constexpr (OP == ICK_OP_CONV_FWD_C4) {
+      const int tap = (k0 + a_k4) >> 2; const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int iy = a_y[i] + r, ix = a_x[i] + s;
+        const bool ok = a_ok[i] && r < p.R && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        ra[i] = ldg4(a_ptr[i] + ((long)iy * p.W + ix) * 4, ok);
+      }
+    } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
+      const int tap = k0 / p.Cout; const int co = k0 - tap * p.Cout + a_k4;
+      const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int ty = a_y[i] - r, tx = a_x[i] - s;
+        const int oy = ty / p.stride, ox = tx / p.stride;
+        const bool ok = a_ok[i] && ty >= 0 && tx >= 0 && oy * p.stride == ty && ox * p.stride == tx &&
+                        oy < p.Ho && ox < p.Wo && (k0 + a_k4 < kend);
+        ra[i] = ldg4(a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co, ok);
+      }
+    } else {  // A [K][M]
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int k = k0 + a_y[i];
+        ra[i] = ldg4(a_ptr[i] + (long)k * p.lda, a_ok[i] && k < kend);
+      }
+    }
+    // ---- B
+    if constexpr (BKc) {
+#pragma unroll
+      for (int i = 0; i < PB; ++i) rb[i] = ldg4k(b_ptr[i] + k0, b_ok[i], k0 + a_k4, kend);
+    } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
+      const int tap = k0 / p.Cout; const int co0 = k0 - tap * p.Cout;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int co = co0 + b_y[i];
+        rb[i] = ldg4(b_ptr[i] + ((long)co * p.R * p.S + tap) * p.Cin, b_ok[i] && (k0 + b_y[i] < kend));
+      }
+    } else if constexpr (OP == ICK_OP_CONV_WGRAD) {
+      const int hw = p.Ho * p.Wo;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int k = k0 + b_y[i];
+        const int b = k / hw; const int rem = k - b * hw; const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        const int iy = oy * p.stride - p.pad + b_r, ix = ox * p.stride - p.pad + b_s;
+        const bool ok = b_ok[i] && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        rb[i] = ldg4(b_ptr[i] + (((long)b * p.H + iy) * p.W + ix) * p.Cin, ok);
+      }
+    } else {  // B [K][N]
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int k = k0 + b_y[i];
+        rb[i] = ldg4(b_ptr[i] + (long)k * p.ldb, b_ok[i] && k < kend);
+      }
+    }
+  };
+
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      if constexpr (AK) {
+        const int x = i * 64 + (tid >> 2);
+        As[buf][a_k4 + 0][x] = ra[i].x; As[buf][a_k4 + 1][x] = ra[i].y;
+        As[buf][a_k4 + 2][x] = ra[i].z; As[buf][a_k4 + 3][x] = ra[i].w;
+      } else {
+        *reinterpret_cast<float4*>(&As[buf][i * A_KR + tid / A_TPK][(tid % A_TPK) * 4]) = ra[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+      if constexpr (BKc) {
+        const int x = i * 64 + (tid >> 2);
+        Bs[buf][a_k4 + 0][x] = rb[i].x; Bs[buf][a_k4 + 1][x] = rb[i].y;
+        Bs[buf][a_k4 + 2][x] = rb[i].z; Bs[buf][a_k4 + 3][x] = rb[i].w;
+      } else {
+        *reinterpret_cast<float4*>(&Bs[buf][i * B_KR + tid / B_TPK][(tid % B_TPK) * 4]) = rb[i];
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (nkt > 0) {
+    fetch(0);
+    stash(0);
+  }
+  __syncthreads();
+
+  const int fa = wm * WM + (lane & 31), fb = wn * WN + (lane & 31), fk = lane >> 5;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) fetch(kt + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float av[TM], bv[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[i] = As[buf][kk + fk][fa + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][kk + fk][fb + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nkt) stash(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* __restrict__ Cg = p.C + coff;
+  const float* __restrict__ Rg = p.residual ? p.residual + coff : nullptr;
+  const bool first_split = (split == 0);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * WN + j * 32 + (lane & 31);
+    const bool nok = n < p.N;
+    const float bias = (p.bias && nok && first_split) ? p.bias[n] : 0.f;
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < p.M && nok) {
+          float v = acc[i][j][r] * p.alpha;
+          ssum += v; ssq += v * v;
+          v = act_fn(v + bias, p.act);
+          const long o = (long)m * p.ldc + n;
+          if (Rg && first_split) v += Rg[(long)m * p.ldr + n];
+          if (p.splitk > 1) atomicAdd(Cg + o, v);
+          else if (p.accumulate) Cg[o] += v;
+          else Cg[o] = v;
+        }
+      }
+    }
+    if (p.stat_sum) {  // BatchNorm batch statistics of the raw product
+      ssum += __shfl_xor(ssum, 32);
+      ssq += __shfl_xor(ssq, 32);
+      if (lane < 32 && nok) { atomicAdd(p.stat_sum + n, ssum); atomicAdd(p.stat_sq + n, ssq); }
+    }
+  }
+}
+
+template <int OP, int BM, int BN>
+int launch(const P& p, int nz, hipStream_t st) {
+  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, nz);
+  hipLaunchKernelGGL((igemm_f32_kernel<OP, BM, BN>), grid, dim3(NT), 0, st, p);
+  return ick::launch_status("igemm_f32");
+}
+
+template <int OP>
+int dispatch_tile(const P& p, int nz, hipStream_t st) {
+  const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nz;
+  // 128x128 tiles when they fill the 256 CUs at least ~1.5x, else 64x64 to get more workgroups
+  if (big >= 384 || (p.M > 64 && p.N > 64 && big >= 192)) return launch<OP, 128, 128>(p, nz, st);
+  return launch<OP, 64, 64>(p, nz, st);
+}
+
+}  // namespace
+
+extern "C" int ick_gemm_f32(const IckGemm* d, void* stream) {
+  ICK_REQUIRE(d != nullptr, "ick_gemm_f32: null descriptor");
+  ICK_REQUIRE(d->A && d->B && d->C, "ick_gemm_f32: null operand pointer");
+  ICK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "ick_gemm_f32: empty problem M=%d N=%d K=%d", d->M, d->N, d->K);
+  ICK_REQUIRE(ick::aligned16(d->A) && ick::aligned16(d->B), "ick_gemm_f32: A/B must be 16-byte aligned");
+  P p{};
+  p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
+  p.stat_sum = d->stat_sum; p.stat_sq = d->stat_sq;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+  const int bo = d->batch_outer > 0 ? d->batch_outer : 1;
+  p.sAo = d->sAo; p.sAi = d->sAi; p.sBo = d->sBo; p.sBi = d->sBi; p.sCo = d->sCo; p.sCi = d->sCi;
+  p.splitk = d->splitk > 1 ? d->splitk : 1;
+  p.accumulate = d->accumulate; p.act = d->act; p.alpha = d->alpha;
+  p.Nb = d->Nb; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
+  int nz = bo * p.batch_inner;
+  ICK_REQUIRE((d->stat_sum == nullptr) == (d->stat_sq == nullptr), "ick_gemm_f32: stat_sum and stat_sq go together");
+  if (p.splitk > 1) {
+    ICK_REQUIRE(nz == 1, "ick_gemm_f32: split-K and batching are exclusive");
+    ICK_REQUIRE(p.act == ICK_ACT_NONE && !p.stat_sum, "ick_gemm_f32: split-K cannot apply an activation or statistics");
+    const int tiles = (p.K + BK - 1) / BK;
+    const int per = (tiles + p.splitk - 1) / p.splitk;
+    p.kps = per * BK;
+    p.splitk = (tiles + per - 1) / per;
+    nz = p.splitk;
+  } else {
+    p.kps = p.K;
+  }
+  ICK_REQUIRE(nz <= 65535, "ick_gemm_f32: grid.z %d too large", nz);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (d->op) {
+    case ICK_OP_NT:
+      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "NT: lda, ldb must be multiples of 4 (rows readable up to roundup4(K))");
+      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "NT: batch strides must be multiples of 4");
+      return dispatch_tile<ICK_OP_NT>(p, nz, st);
+    case ICK_OP_NN:
+      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "NN: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
+      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "NN: batch strides must be multiples of 4");
+      return dispatch_tile<ICK_OP_NN>(p, nz, st);
+    case ICK_OP_TN:
+      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "TN: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
+      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "TN: batch strides must be multiples of 4");
+      return dispatch_tile<ICK_OP_TN>(p, nz, st);
+    case ICK_OP_CONV_FWD:
+      ICK_REQUIRE(p.Cin % BK == 0, "CONV_FWD: Cin=%d must be a multiple of %d", p.Cin, BK);
+      ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * p.Cin && p.ldb == p.K,
+                  "CONV_FWD: M/N/K do not match the geometry");
+      return dispatch_tile<ICK_OP_CONV_FWD>(p, nz, st);
+    case ICK_OP_CONV_FWD_C4:
+      ICK_REQUIRE(p.Cin == 4, "CONV_FWD_C4: Cin must be 4");
+      ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * 4 && p.ldb == p.K,
+                  "CONV_FWD_C4: M/N/K do not match the geometry");
+      return dispatch_tile<ICK_OP_CONV_FWD_C4>(p, nz, st);
+    case ICK_OP_CONV_DGRAD:
+      ICK_REQUIRE(p.Cout % BK == 0 && p.Cin % 4 == 0, "CONV_DGRAD: Cout %% 16 and Cin %% 4 required");
+      ICK_REQUIRE(p.M == p.Nb * p.H * p.W && p.N == p.Cin && p.K == p.R * p.S * p.Cout,
+                  "CONV_DGRAD: M/N/K do not match the geometry");
+      return dispatch_tile<ICK_OP_CONV_DGRAD>(p, nz, st);
+    case ICK_OP_CONV_WGRAD:
+      ICK_REQUIRE(p.Cout % 4 == 0 && p.Cin % 4 == 0, "CONV_WGRAD: Cout %% 4 and Cin %% 4 required");
+      ICK_REQUIRE(p.M == p.Cout && p.N == p.R * p.S * p.Cin && p.K == p.Nb * p.Ho * p.Wo && p.lda == p.Cout,
+                  "CONV_WGRAD: M/N/K do not match the geometry");
+      return dispatch_tile<ICK_OP_CONV_WGRAD>(p, nz, st);
+    default:
+      return ick::fail(-1, "ick_gemm_f32: unknown op %d", d->op);
+  }
+}

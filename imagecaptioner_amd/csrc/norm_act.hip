@@ -1,0 +1,574 @@
+// norm_act.hip — the HBM-bound companions of the contraction kernels: BatchNorm (train/eval,
+// fwd/bwd), LayerNorm fwd/bwd, row softmax fwd/bwd, max-pool, layout transforms, column sums,
+// embedding gather/scatter, adaptive token pooling.  All fp32, float4-vectorised along the
+// contiguous (channel / feature) axis, grid-stride loops capped at ~2048 workgroups, wave64
+// shuffles for reductions.
+#include "ick_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+inline int grid_for(long work_items, int per_block = NT, int cap = 2048) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// ------------------------------------------------------------------ layout transforms
+// images (B,3,H,W) fp32 NCHW -> (B,H,W,4) NHWC with a zero 4th channel (16-B pixels for the stem conv)
+__global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, long npix, long hw) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / hw, r = i - b * hw;
+    const float* s = x + b * 3 * hw + r;
+    reinterpret_cast<float4*>(y)[i] = make_float4(s[0], s[hw], s[2 * hw], 0.f);
+  }
+}
+
+// images (B,3,224,224) -> rows [B*196][768], k = c*256 + py*16 + px (the flattened Conv2d(3,384,16,16) weight order)
+__global__ void patchify16_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int HW, int G) {
+  const long total4 = (long)B * G * G * 192;  // float4 units
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i % 192);
+    const long pr = i / 192;
+    const int gx = (int)(pr % G), gy = (int)((pr / G) % G);
+    const long b = pr / ((long)G * G);
+    const int c = q >> 6, py = (q >> 2) & 15, px = (q & 3) * 4;
+    const float* s = x + ((b * 3 + c) * HW + gy * 16 + py) * (long)HW + gx * 16 + px;
+    reinterpret_cast<float4*>(y)[i] = *reinterpret_cast<const float4*>(s);
+  }
+}
+
+// ViT token assembly: x[b][0] = cls + pos[0]; x[b][1+p] = patch[b][p] + pos[1+p]
+__global__ void vit_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
+                                    const float* __restrict__ pos, float* __restrict__ x, int B, int Ntok, int D4) {
+  const long total = (long)B * Ntok * D4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D4);
+    const long r = i / D4;
+    const int tkn = (int)(r % Ntok);
+    const long b = r / Ntok;
+    const float4 pe = reinterpret_cast<const float4*>(pos)[(long)tkn * D4 + d];
+    float4 v = tkn == 0 ? reinterpret_cast<const float4*>(cls)[d]
+                        : reinterpret_cast<const float4*>(patch)[(b * (Ntok - 1) + tkn - 1) * D4 + d];
+    v.x += pe.x; v.y += pe.y; v.z += pe.z; v.w += pe.w;
+    reinterpret_cast<float4*>(x)[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ BatchNorm
+// finalize batch statistics gathered by the conv epilogue: mean/var -> (scale, shift), saved mean / invstd,
+// running-stat update with the unbiased variance (nn.BatchNorm2d train mode, momentum 0.1)
+__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
+                                   float* __restrict__ sinv, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = sum[c] / count;
+  float var = sq[c] / count - mean * mean;
+  var = var > 0.f ? var : 0.f;
+  const float inv = rsqrtf(var + eps);
+  const float g = gamma[c];
+  scale[c] = g * inv;
+  shift[c] = beta[c] - mean * g * inv;
+  smean[c] = mean;
+  sinv[c] = inv;
+  if (rmean) {
+    const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+  }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float inv = rsqrtf(rvar[c] + eps);
+  scale[c] = gamma[c] * inv;
+  shift[c] = beta[c] - rmean[c] * gamma[c] * inv;
+}
+
+// y = [relu](x*scale[c] + shift[c] [+ residual]); x,y [M][C] (NHWC rows)
+__global__ void scale_shift_act_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                       const float* __restrict__ shift, const float* __restrict__ res,
+                                       float* __restrict__ y, long total4, int C4, int relu) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 a = reinterpret_cast<const float4*>(scale)[c];
+    const float4 b = reinterpret_cast<const float4*>(shift)[c];
+    float4 o = make_float4(fmaf(v.x, a.x, b.x), fmaf(v.y, a.y, b.y), fmaf(v.z, a.z, b.z), fmaf(v.w, a.w, b.w));
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
+// BN backward pass 1: per channel sum(g) and sum(g * xhat), g = dy * (y > 0) when y != NULL.
+// Block = 256 threads as (ROWS x C4 lanes); each thread owns 4 channels, strides over rows; LDS combine, atomics out.
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                     const float* __restrict__ x, const float* __restrict__ mean,
+                                     const float* __restrict__ inv, float* __restrict__ sum_g,
+                                     float* __restrict__ sum_gx, long M, int C) {
+  const int C4 = C >> 2;
+  const int lanes = C4 < NT ? C4 : NT;     // threads along channels
+  const int rows = NT / lanes;             // threads along rows
+  const int tc = threadIdx.x % lanes, tr = threadIdx.x / lanes;
+  __shared__ float4 sh_g[NT], sh_x[NT];
+  for (int c4 = blockIdx.x * lanes + tc; c4 < C4; c4 += gridDim.x * lanes) {
+    const float4 mu = reinterpret_cast<const float4*>(mean)[c4];
+    const float4 iv = reinterpret_cast<const float4*>(inv)[c4];
+    float4 ag = make_float4(0, 0, 0, 0), ax = make_float4(0, 0, 0, 0);
+    if (tr < rows) {
+      for (long m = blockIdx.y * (long)rows + tr; m < M; m += (long)gridDim.y * rows) {
+        const long o = m * C4 + c4;
+        float4 g = reinterpret_cast<const float4*>(dy)[o];
+        if (y) {
+          const float4 yy = reinterpret_cast<const float4*>(y)[o];
+          g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+          g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+        }
+        const float4 xv = reinterpret_cast<const float4*>(x)[o];
+        ag.x += g.x; ag.y += g.y; ag.z += g.z; ag.w += g.w;
+        ax.x += g.x * (xv.x - mu.x) * iv.x; ax.y += g.y * (xv.y - mu.y) * iv.y;
+        ax.z += g.z * (xv.z - mu.z) * iv.z; ax.w += g.w * (xv.w - mu.w) * iv.w;
+      }
+    }
+    sh_g[threadIdx.x] = ag; sh_x[threadIdx.x] = ax;
+    __syncthreads();
+    if (tr == 0) {
+      for (int r = 1; r < rows; ++r) {
+        const float4 a = sh_g[r * lanes + tc], b = sh_x[r * lanes + tc];
+        ag.x += a.x; ag.y += a.y; ag.z += a.z; ag.w += a.w;
+        ax.x += b.x; ax.y += b.y; ax.z += b.z; ax.w += b.w;
+      }
+      float* sg = sum_g + c4 * 4; float* sx = sum_gx + c4 * 4;
+      atomicAdd(sg + 0, ag.x); atomicAdd(sg + 1, ag.y); atomicAdd(sg + 2, ag.z); atomicAdd(sg + 3, ag.w);
+      atomicAdd(sx + 0, ax.x); atomicAdd(sx + 1, ax.y); atomicAdd(sx + 2, ax.z); atomicAdd(sx + 3, ax.w);
+    }
+    __syncthreads();
+  }
+}
+
+// BN backward pass 2: dx = gamma*inv*(g - sum_g/M - xhat*sum_gx/M); optionally also writes g (the gradient that
+// flows on into the residual branch).  In eval mode (use_batch_stats == 0): dx = gamma*inv*g.
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                    const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ inv, const float* __restrict__ gamma,
+                                    const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float invM,
+                                    float* __restrict__ dx, float* __restrict__ gout, long total4, int C4,
+                                    int use_batch_stats) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    float4 g = reinterpret_cast<const float4*>(dy)[i];
+    if (y) {
+      const float4 yy = reinterpret_cast<const float4*>(y)[i];
+      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
+      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+    }
+    if (gout) reinterpret_cast<float4*>(gout)[i] = g;
+    const float4 ga = reinterpret_cast<const float4*>(gamma)[c];
+    const float4 iv = reinterpret_cast<const float4*>(inv)[c];
+    float4 o;
+    if (use_batch_stats) {
+      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      const float4 mu = reinterpret_cast<const float4*>(mean)[c];
+      const float4 sg = reinterpret_cast<const float4*>(sum_g)[c];
+      const float4 sx = reinterpret_cast<const float4*>(sum_gx)[c];
+      o.x = ga.x * iv.x * (g.x - sg.x * invM - (xv.x - mu.x) * iv.x * sx.x * invM);
+      o.y = ga.y * iv.y * (g.y - sg.y * invM - (xv.y - mu.y) * iv.y * sx.y * invM);
+      o.z = ga.z * iv.z * (g.z - sg.z * invM - (xv.z - mu.z) * iv.z * sx.z * invM);
+      o.w = ga.w * iv.w * (g.w - sg.w * invM - (xv.w - mu.w) * iv.w * sx.w * invM);
+    } else {
+      o = make_float4(ga.x * iv.x * g.x, ga.y * iv.y * g.y, ga.z * iv.z * g.z, ga.w * iv.w * g.w);
+    }
+    reinterpret_cast<float4*>(dx)[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------ max-pool 3x3 / stride 2 / pad 1, NHWC
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
+                                    int Ho, int Wo) {
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long b = r / Ho;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int iy = oy * 2 - 1 + dy;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int ix = ox * 2 - 1 + dx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float4 v = reinterpret_cast<const float4*>(x)[((b * H + iy) * W + ix) * C4 + c];
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    reinterpret_cast<float4*>(y)[i] = m;
+  }
+}
+
+// ------------------------------------------------------------------ LayerNorm (one wave per row)
+__global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                     const float* __restrict__ b, float* __restrict__ y, float* __restrict__ mean_out,
+                                     float* __restrict__ rstd_out, long rows, int D, float eps) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int D4 = D >> 2;
+  for (long r = blockIdx.x * (long)wpb + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * wpb) {
+    const float4* xr = reinterpret_cast<const float4*>(x + r * D);
+    float s = 0.f;
+    for (int i = lane; i < D4; i += 64) { const float4 v = xr[i]; s += (v.x + v.y) + (v.z + v.w); }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+    for (int i = lane; i < D4; i += 64) {
+      const float4 v = xr[i];
+      const float a = v.x - mu, c = v.y - mu, d = v.z - mu, e = v.w - mu;
+      q += (a * a + c * c) + (d * d + e * e);
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    float4* yr = reinterpret_cast<float4*>(y + r * D);
+    for (int i = lane; i < D4; i += 64) {
+      const float4 v = xr[i];
+      const float4 gg = reinterpret_cast<const float4*>(g)[i], bb = reinterpret_cast<const float4*>(b)[i];
+      yr[i] = make_float4((v.x - mu) * rs * gg.x + bb.x, (v.y - mu) * rs * gg.y + bb.y,
+                          (v.z - mu) * rs * gg.z + bb.z, (v.w - mu) * rs * gg.w + bb.w);
+    }
+    if (lane == 0 && mean_out) { mean_out[r] = mu; rstd_out[r] = rs; }
+  }
+}
+
+// dx per row (one wave per row); dgamma/dbeta: per-block partial sums in LDS then atomics
+__global__ void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                     const float* __restrict__ g, const float* __restrict__ mean,
+                                     const float* __restrict__ rstd, float* __restrict__ dx,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, long rows, int D) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [2][D]
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) sh[i] = 0.f;
+  __syncthreads();
+  for (long r = blockIdx.x * (long)wpb + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * wpb) {
+    const float mu = mean[r], rs = rstd[r];
+    const float* xr = x + r * D; const float* dr = dy + r * D;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < D; i += 64) {
+      const float xh = (xr[i] - mu) * rs, dg = dr[i] * g[i];
+      s1 += dg; s2 += dg * xh;
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+    for (int i = lane; i < D; i += 64) {
+      const float xh = (xr[i] - mu) * rs, d = dr[i];
+      dx[r * D + i] = rs * (d * g[i] - s1 - xh * s2);
+      if (dgamma) { atomicAdd(&sh[i], d * xh); atomicAdd(&sh[D + i], d); }
+    }
+  }
+  __syncthreads();
+  if (dgamma)
+    for (int i = threadIdx.x; i < D; i += blockDim.x) { atomicAdd(dgamma + i, sh[i]); atomicAdd(dbeta + i, sh[D + i]); }
+}
+
+// ------------------------------------------------------------------ row softmax (attention scores), in place
+// s[row][0..L) <- softmax(scale * s) ; causal: columns > (row % Lq) are masked out
+__global__ void softmax_rows_kernel(float* __restrict__ s, long rows, int L, int ld, float scale, int causal, int Lq) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  for (long r = blockIdx.x * (long)wpb + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * wpb) {
+    float* sr = s + r * ld;
+    const int lim = causal ? (int)(r % Lq) + 1 : L;
+    float mx = -INFINITY;
+    for (int i = lane; i < lim; i += 64) mx = fmaxf(mx, sr[i] * scale);
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int i = lane; i < lim; i += 64) sum += expf(sr[i] * scale - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int i = lane; i < ld; i += 64) sr[i] = i < lim ? expf(sr[i] * scale - mx) * inv : 0.f;  // pad columns [L, ld) zeroed
+  }
+}
+
+// dS = scale * P * (dP - sum_j dP_j P_j), in place on dP
+__global__ void softmax_bwd_rows_kernel(float* __restrict__ dp, const float* __restrict__ p, long rows, int L, int ld,
+                                        float scale) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  for (long r = blockIdx.x * (long)wpb + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * wpb) {
+    float* dr = dp + r * ld; const float* pr = p + r * ld;
+    float d = 0.f;
+    for (int i = lane; i < L; i += 64) d += dr[i] * pr[i];
+    d = wave_sum(d);
+    for (int i = lane; i < ld; i += 64) dr[i] = i < L ? scale * pr[i] * (dr[i] - d) : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ small utilities
+// out[n] (+)= sum_m x[m][n]   (bias gradients); grid.y strides over rows, atomics combine
+__global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long M, int N, long ld) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (long m = blockIdx.y; m < M; m += gridDim.y) s += x[m * ld + n];
+  atomicAdd(out + n, s);
+}
+
+// dx = dy * (y > 0)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
+                                long total4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    float4 g = reinterpret_cast<const float4*>(dy)[i];
+    const float4 yy = reinterpret_cast<const float4*>(y)[i];
+    g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f; g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+    reinterpret_cast<float4*>(dx)[i] = g;
+  }
+}
+
+// y = a + b (float4)
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, long total4) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+    reinterpret_cast<float4*>(y)[i] = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
+  }
+}
+
+// embedding gather: out[i][:] = table[ids[i]][:] (+ pe[i / per_pos][:] when pe != NULL: sinusoid rows by position)
+__global__ void embedding_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ table,
+                                     const float* __restrict__ pe, float* __restrict__ out, long n, int D4, int per_pos) {
+  const long total = n * D4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D4; const int d = (int)(i - r * D4);
+    float4 v = reinterpret_cast<const float4*>(table)[ids[r] * D4 + d];
+    if (pe) {
+      const float4 e = reinterpret_cast<const float4*>(pe)[(r / per_pos) * D4 + d];
+      v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+// embedding backward: dtable[ids[i]][:] += dout[i][:]
+__global__ void embedding_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dout,
+                                     float* __restrict__ dtable, long n, int D) {
+  const long total = n * D;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / D; const int d = (int)(i - r * D);
+    atomicAdd(dtable + ids[r] * D + d, dout[i]);
+  }
+}
+
+// adaptive average pooling along tokens: x (B,L,D) -> y (B,Lo,D), bin i = [floor(i*L/Lo), ceil((i+1)*L/Lo))
+__global__ void token_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int L, int Lo, int D4) {
+  const long total = (long)B * Lo * D4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D4); const long r = i / D4; const int o = (int)(r % Lo); const long b = r / Lo;
+    const int a = (o * L) / Lo, e = ((o + 1) * L + Lo - 1) / Lo;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int t = a; t < e; ++t) {
+      const float4 v = reinterpret_cast<const float4*>(x)[(b * L + t) * D4 + d];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float inv = 1.f / (e - a);
+    reinterpret_cast<float4*>(y)[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+
+// backward: dx[b][t] = sum over bins o containing t of dy[b][o] / |bin o|
+__global__ void token_pool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int L, int Lo, int D4) {
+  const long total = (long)B * L * D4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(i % D4); const long r = i / D4; const int t = (int)(r % L); const long b = r / L;
+    float4 s = make_float4(0, 0, 0, 0);
+    // candidate bins: o with floor(o*L/Lo) <= t < ceil((o+1)*L/Lo)
+    int o_lo = (int)(((long)t * Lo) / L) - 1; if (o_lo < 0) o_lo = 0;
+    for (int o = o_lo; o < Lo && (o * L) / Lo <= t; ++o) {
+      const int a = (o * L) / Lo, e = ((o + 1) * L + Lo - 1) / Lo;
+      if (t >= a && t < e) {
+        const float inv = 1.f / (e - a);
+        const float4 v = reinterpret_cast<const float4*>(dy)[(b * Lo + o) * D4 + d];
+        s.x += v.x * inv; s.y += v.y * inv; s.z += v.z * inv; s.w += v.w * inv;
+      }
+    }
+    reinterpret_cast<float4*>(dx)[i] = s;
+  }
+}
+
+}  // namespace
+
+#define ST static_cast<hipStream_t>(stream)
+
+extern "C" {
+
+int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stream) {
+  ICK_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "ick_nchw3_to_nhwc4: bad arguments");
+  const long npix = (long)B * H * W;
+  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(grid_for(npix)), dim3(NT), 0, ST, x, y, npix, (long)H * W);
+  return ick::launch_status("nchw3_to_nhwc4");
+}
+
+int ick_patchify16(const float* x, float* y, int B, int HW, void* stream) {
+  ICK_REQUIRE(x && y && B > 0 && HW % 16 == 0, "ick_patchify16: bad arguments");
+  const int G = HW / 16;
+  hipLaunchKernelGGL(patchify16_kernel, dim3(grid_for((long)B * G * G * 192)), dim3(NT), 0, ST, x, y, B, HW, G);
+  return ick::launch_status("patchify16");
+}
+
+int ick_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int Ntok, int D, void* stream) {
+  ICK_REQUIRE(patch && cls && pos && x && D % 4 == 0, "ick_vit_assemble: bad arguments");
+  hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for((long)B * Ntok * (D / 4))), dim3(NT), 0, ST, patch, cls, pos, x, B,
+                     Ntok, D / 4);
+  return ick::launch_status("vit_assemble");
+}
+
+int ick_bn_finalize(const float* sum, const float* sq, float count, const float* gamma, const float* beta, float* rmean,
+                    float* rvar, float momentum, float eps, float* scale, float* shift, float* save_mean,
+                    float* save_invstd, int C, void* stream) {
+  ICK_REQUIRE(sum && sq && gamma && beta && scale && shift && save_mean && save_invstd && C > 0 && count > 0,
+              "ick_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum, sq, count, gamma, beta, rmean, rvar,
+                     momentum, eps, scale, shift, save_mean, save_invstd, C);
+  return ick::launch_status("bn_finalize");
+}
+
+int ick_bn_eval_coeffs(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                       float* scale, float* shift, int C, void* stream) {
+  ICK_REQUIRE(gamma && beta && rmean && rvar && scale && shift && C > 0, "ick_bn_eval_coeffs: bad arguments");
+  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, gamma, beta, rmean, rvar, eps, scale,
+                     shift, C);
+  return ick::launch_status("bn_eval_coeffs");
+}
+
+int ick_scale_shift_act(const float* x, const float* scale, const float* shift, const float* residual, float* y, long M,
+                        int C, int relu, void* stream) {
+  ICK_REQUIRE(x && scale && shift && y && C % 4 == 0 && M > 0, "ick_scale_shift_act: bad arguments (C %% 4)");
+  const long total4 = M * (C / 4);
+  hipLaunchKernelGGL(scale_shift_act_kernel, dim3(grid_for(total4)), dim3(NT), 0, ST, x, scale, shift, residual, y, total4,
+                     C / 4, relu);
+  return ick::launch_status("scale_shift_act");
+}
+
+int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                      float* sum_g, float* sum_gx, long M, int C, void* stream) {
+  ICK_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && C % 4 == 0 && M > 0, "ick_bn_bwd_reduce: bad arguments");
+  const int C4 = C / 4;
+  const int lanes = C4 < NT ? C4 : NT;
+  ICK_REQUIRE(NT % lanes == 0, "ick_bn_bwd_reduce: C/4=%d must divide %d or be a multiple of it", C4, NT);
+  const int rows = NT / lanes;
+  const int gx = (C4 + lanes - 1) / lanes;
+  long gy = (M + rows * 32 - 1) / (rows * 32);   // ~32 rows per thread
+  if (gy > 512) gy = 512;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, M, C);
+  return ick::launch_status("bn_bwd_reduce");
+}
+
+int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                     const float* gamma, const float* sum_g, const float* sum_gx, float* dx, float* g_out, long M, int C,
+                     int use_batch_stats, void* stream) {
+  ICK_REQUIRE(dy && x && mean && invstd && gamma && dx && C % 4 == 0 && M > 0, "ick_bn_bwd_apply: bad arguments");
+  const long total4 = M * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, sum_g,
+                     sum_gx, 1.0f / (float)M, dx, g_out, total4, C / 4, use_batch_stats);
+  return ick::launch_status("bn_bwd_apply");
+}
+
+int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+  ICK_REQUIRE(x && y && C % 4 == 0, "ick_maxpool3x3s2: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(NT), 0, ST, x, y, B, H, W, C / 4,
+                     Ho, Wo);
+  return ick::launch_status("maxpool3x3s2");
+}
+
+int ick_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows,
+                      int D, float eps, void* stream) {
+  ICK_REQUIRE(x && gamma && beta && y && D % 4 == 0 && rows > 0, "ick_layernorm_fwd: bad arguments (D %% 4)");
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, x, gamma, beta, y, mean, rstd, rows, D, eps);
+  return ick::launch_status("layernorm_fwd");
+}
+
+int ick_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                      float* dgamma, float* dbeta, long rows, int D, void* stream) {
+  ICK_REQUIRE(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0 && D <= 4096, "ick_layernorm_bwd: bad arguments");
+  ICK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "ick_layernorm_bwd: dgamma and dbeta go together");
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid_for(rows, 16, 1024)), dim3(NT), 2 * D * sizeof(float), ST, dy, x, gamma,
+                     mean, rstd, dx, dgamma, dbeta, rows, D);
+  return ick::launch_status("layernorm_bwd");
+}
+
+int ick_softmax_rows(float* s, long rows, int L, int ld, float scale, int causal, int Lq, void* stream) {
+  ICK_REQUIRE(s && rows > 0 && L > 0 && ld >= L && (!causal || Lq > 0), "ick_softmax_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, s, rows, L, ld, scale, causal, Lq);
+  return ick::launch_status("softmax_rows");
+}
+
+int ick_softmax_bwd_rows(float* dp, const float* p, long rows, int L, int ld, float scale, void* stream) {
+  ICK_REQUIRE(dp && p && rows > 0 && L > 0 && ld >= L, "ick_softmax_bwd_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, dp, p, rows, L, ld, scale);
+  return ick::launch_status("softmax_bwd_rows");
+}
+
+int ick_colsum(const float* x, float* out, long M, int N, long ld, void* stream) {
+  ICK_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, "ick_colsum: bad arguments");
+  long gy = (M + 63) / 64; if (gy > 256) gy = 256;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + NT - 1) / NT, (int)gy), dim3(NT), 0, ST, x, out, M, N, ld);
+  return ick::launch_status("colsum");
+}
+
+int ick_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream) {
+  ICK_REQUIRE(dy && y && dx && n % 4 == 0, "ick_relu_bwd: n %% 4");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, ST, dy, y, dx, n / 4);
+  return ick::launch_status("relu_bwd");
+}
+
+int ick_add(const float* a, const float* b, float* y, long n, void* stream) {
+  ICK_REQUIRE(a && b && y && n % 4 == 0, "ick_add: n %% 4");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, ST, a, b, y, n / 4);
+  return ick::launch_status("add");
+}
+
+int ick_embedding_fwd(const int64_t* ids, const float* table, const float* pe, float* out, long n, int D, int per_pos,
+                      void* stream) {
+  ICK_REQUIRE(ids && table && out && D % 4 == 0 && n > 0, "ick_embedding_fwd: bad arguments");
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(n * (D / 4))), dim3(NT), 0, ST, (const long*)ids, table, pe, out, n,
+                     D / 4, per_pos > 0 ? per_pos : 1);
+  return ick::launch_status("embedding_fwd");
+}
+
+int ick_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, long n, int D, void* stream) {
+  ICK_REQUIRE(ids && dout && dtable && n > 0 && D > 0, "ick_embedding_bwd: bad arguments");
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(n * D)), dim3(NT), 0, ST, (const long*)ids, dout, dtable, n, D);
+  return ick::launch_status("embedding_bwd");
+}
+
+int ick_token_pool_fwd(const float* x, float* y, int B, int L, int Lo, int D, void* stream) {
+  ICK_REQUIRE(x && y && D % 4 == 0 && Lo > 0 && L >= Lo, "ick_token_pool_fwd: bad arguments");
+  hipLaunchKernelGGL(token_pool_fwd_kernel, dim3(grid_for((long)B * Lo * (D / 4))), dim3(NT), 0, ST, x, y, B, L, Lo, D / 4);
+  return ick::launch_status("token_pool_fwd");
+}
+
+int ick_token_pool_bwd(const float* dy, float* dx, int B, int L, int Lo, int D, void* stream) {
+  ICK_REQUIRE(dy && dx && D % 4 == 0 && Lo > 0 && L >= Lo, "ick_token_pool_bwd: bad arguments");
+  hipLaunchKernelGGL(token_pool_bwd_kernel, dim3(grid_for((long)B * L * (D / 4))), dim3(NT), 0, ST, dy, dx, B, L, Lo, D / 4);
+  return ick::launch_status("token_pool_bwd");
+}
+
+}  // extern "C"

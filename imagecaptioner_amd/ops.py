@@ -1,0 +1,349 @@
+"""Tensor-level launchers over the C ABI (include/ick.h).  PyTorch supplies device memory
+(torch.empty), the current HIP stream and nothing else; every function here ends in a
+libick.so kernel launch on that stream, so the whole step can be captured in a hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH, OP_CONV_DGRAD, OP_CONV_FWD, OP_CONV_FWD_C4,
+                   OP_CONV_WGRAD, OP_NN, OP_NT, OP_TN, IckGemm, check)
+
+_F32 = torch.float32
+
+
+def _st() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: the HIP path needs a device tensor (no CPU fallback exists)")
+    if t.dtype != _F32:
+        raise TypeError(f"{name}: expected float32, got {t.dtype}")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def empty(*shape, device=None) -> torch.Tensor:
+    return torch.empty(*shape, dtype=_F32, device=device or "cuda")
+
+
+def zeros(*shape, device=None) -> torch.Tensor:
+    return torch.zeros(*shape, dtype=_F32, device=device or "cuda")
+
+
+# ----------------------------------------------------------------------------- raw GEMM
+def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *,
+             bias: Optional[int] = None, residual: Optional[int] = None, ldr: int = 0, act: int = ACT_NONE,
+             alpha: float = 1.0, batch: Tuple[int, int] = (1, 1),
+             strides: Tuple[int, int, int, int, int, int] = (0, 0, 0, 0, 0, 0), splitk: int = 1,
+             accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
+             conv: Optional[Tuple[int, ...]] = None) -> None:
+    d = IckGemm()
+    d.A, d.B, d.C = A, B, C
+    d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
+    d.op, d.act = op, act
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.batch_outer, d.batch_inner = batch
+    d.sAo, d.sAi, d.sBo, d.sBi, d.sCo, d.sCi = strides
+    d.splitk, d.accumulate, d.alpha = splitk, int(accumulate), alpha
+    if conv is not None:
+        d.Nb, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.R, d.S, d.stride, d.pad = conv
+    check(_lib.lib().ick_gemm_f32(ctypes.byref(d), _st()), "ick_gemm_f32")
+
+
+# ----------------------------------------------------------------------------- Linear
+def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = act(x @ w.T + bias) + residual ; x (..., K) contiguous, w (N, K)."""
+    _chk(x, "x"); _chk(w, "w")
+    K = x.shape[-1]
+    N = w.shape[0]
+    M = x.numel() // K
+    assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
+    y = out if out is not None else empty(*x.shape[:-1], N, device=x.device)
+    gemm_raw(OP_NT, x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, N, bias=_ptr(bias),
+             residual=_ptr(residual), ldr=N, act=act)
+    return y
+
+
+def linear_bwd_data(dy: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None,
+                    accumulate: bool = False) -> torch.Tensor:
+    """dx = dy @ w ; dy (..., N), w (N, K)."""
+    N, K = w.shape
+    M = dy.numel() // N
+    assert dy.is_contiguous() and w.is_contiguous()
+    dx = out if out is not None else empty(*dy.shape[:-1], K, device=dy.device)
+    gemm_raw(OP_NN, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), M, K, N, N, K, K, accumulate=accumulate)
+    return dx
+
+
+def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, splitk: int = 0) -> None:
+    """dw (N, K) += dy^T @ x (accumulates into dw, like autograd's .grad)."""
+    N, K = dw.shape
+    M = dy.numel() // N
+    assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
+    if splitk <= 0:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splitk = max(1, min(32, 512 // max(tiles, 1), M // 256))
+    if splitk > 1:
+        gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, K, M, N, K, K, splitk=splitk)
+    else:
+        gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, K, M, N, K, K, accumulate=True)
+
+
+def colsum_into(x: torch.Tensor, out: torch.Tensor) -> None:
+    """out[n] += sum over rows of x (…, N)."""
+    N = x.shape[-1]
+    check(_lib.lib().ick_colsum(x.data_ptr(), out.data_ptr(), x.numel() // N, N, N, _st()), "ick_colsum")
+
+
+def relu_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    dx = torch.empty_like(dy)
+    check(_lib.lib().ick_relu_bwd(dy.data_ptr(), y.data_ptr(), dx.data_ptr(), dy.numel(), _st()), "ick_relu_bwd")
+    return dx
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    y = out if out is not None else torch.empty_like(a)
+    check(_lib.lib().ick_add(a.data_ptr(), b.data_ptr(), y.data_ptr(), a.numel(), _st()), "ick_add")
+    return y
+
+
+# ----------------------------------------------------------------------------- LayerNorm
+def layernorm_fwd(x: torch.Tensor, g: torch.Tensor, b: torch.Tensor, eps: float, save: bool = True):
+    D = x.shape[-1]
+    rows = x.numel() // D
+    y = torch.empty_like(x)
+    mean = empty(rows, device=x.device) if save else None
+    rstd = empty(rows, device=x.device) if save else None
+    check(_lib.lib().ick_layernorm_fwd(x.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), _ptr(mean), _ptr(rstd),
+                                       rows, D, eps, _st()), "ick_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, g, mean, rstd, dg: Optional[torch.Tensor], db: Optional[torch.Tensor]) -> torch.Tensor:
+    D = x.shape[-1]
+    dx = torch.empty_like(x)
+    check(_lib.lib().ick_layernorm_bwd(dy.data_ptr(), x.data_ptr(), g.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                       dx.data_ptr(), _ptr(dg), _ptr(db), x.numel() // D, D, _st()), "ick_layernorm_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------- attention core (unfused: GEMM + softmax + GEMM)
+def attention_fwd(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, koff: int, kld: int, v: torch.Tensor, voff: int,
+                  vld: int, B: int, H: int, Lq: int, Lk: int, d: int, causal: bool = False):
+    """softmax(Q K^T / sqrt(d)) V per (batch, head).  q/k/v are 2-D row matrices [(B*L)][ld] in which head h of
+    the operand starts at column off + h*d (packed in_proj outputs).  Returns (O [B*Lq][H*d], P [B,H,Lq,Lkp]) with
+    the probability rows padded to Lkp = roundup4(Lk) (pad columns are zero)."""
+    E = H * d
+    Lkp = (Lk + 3) // 4 * 4
+    P = empty(B, H, Lq, Lkp, device=q.device)
+    O = empty(B * Lq, E, device=q.device)
+    fs = 4  # bytes per float
+    gemm_raw(OP_NT, q.data_ptr() + qoff * fs, k.data_ptr() + koff * fs, P.data_ptr(), Lq, Lk, d, qld, kld, Lkp,
+             batch=(B, H), strides=(Lq * qld, d, Lk * kld, d, H * Lq * Lkp, Lq * Lkp))
+    check(_lib.lib().ick_softmax_rows(P.data_ptr(), B * H * Lq, Lk, Lkp, 1.0 / math.sqrt(d), int(causal), Lq, _st()),
+          "ick_softmax_rows")
+    gemm_raw(OP_NN, P.data_ptr(), v.data_ptr() + voff * fs, O.data_ptr(), Lq, d, Lk, Lkp, vld, E,
+             batch=(B, H), strides=(H * Lq * Lkp, Lq * Lkp, Lk * vld, d, Lq * E, d))
+    return O, P
+
+
+def attention_bwd(dO: torch.Tensor, P: torch.Tensor, q, qoff, qld, k, koff, kld, v, voff, vld,
+                  dq, dqoff, dqld, dk, dkoff, dkld, dv, dvoff, dvld, B, H, Lq, Lk, d):
+    """Backward of attention_fwd; writes dQ/dK/dV into the given row matrices at the same packed offsets."""
+    E = H * d
+    fs = 4
+    Lkp = P.shape[-1]
+    dP = torch.empty_like(P)
+    sP = (H * Lq * Lkp, Lq * Lkp)
+    # dP = dO V^T
+    gemm_raw(OP_NT, dO.data_ptr(), v.data_ptr() + voff * fs, dP.data_ptr(), Lq, Lk, d, E, vld, Lkp,
+             batch=(B, H), strides=(Lq * E, d, Lk * vld, d) + sP)
+    # dV = P^T dO
+    gemm_raw(OP_TN, P.data_ptr(), dO.data_ptr(), dv.data_ptr() + dvoff * fs, Lk, d, Lq, Lkp, E, dvld,
+             batch=(B, H), strides=sP + (Lq * E, d, Lk * dvld, d))
+    # dS = scale * P * (dP - rowsum(dP*P))
+    check(_lib.lib().ick_softmax_bwd_rows(dP.data_ptr(), P.data_ptr(), B * H * Lq, Lk, Lkp, 1.0 / math.sqrt(d), _st()),
+          "ick_softmax_bwd_rows")
+    # dQ = dS K
+    gemm_raw(OP_NN, dP.data_ptr(), k.data_ptr() + koff * fs, dq.data_ptr() + dqoff * fs, Lq, d, Lk, Lkp, kld, dqld,
+             batch=(B, H), strides=sP + (Lk * kld, d, Lq * dqld, d))
+    # dK = dS^T Q
+    gemm_raw(OP_TN, dP.data_ptr(), q.data_ptr() + qoff * fs, dk.data_ptr() + dkoff * fs, Lk, d, Lq, Lkp, qld, dkld,
+             batch=(B, H), strides=sP + (Lq * qld, d, Lk * dkld, d))
+
+
+# ----------------------------------------------------------------------------- convolution (NHWC implicit GEMM)
+def conv_out_hw(H: int, W: int, R: int, S: int, stride: int, pad: int) -> Tuple[int, int]:
+    return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+
+
+def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+             ) -> torch.Tensor:
+    """x (Nb,H,W,Cin) physical NHWC contiguous; w physical (Cout,R,S,Cin); returns raw y (Nb,Ho,Wo,Cout) and
+    optionally accumulates per-channel sum / sum of squares (BatchNorm batch statistics) into `stats`."""
+    Nb, H, W, Cin = x.shape
+    Cout, R, S, Cin2 = w.shape
+    assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous()
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
+    y = empty(Nb, Ho, Wo, Cout, device=x.device)
+    op = OP_CONV_FWD_C4 if Cin == 4 else OP_CONV_FWD
+    K = R * S * Cin
+    gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout,
+             stat_sum=_ptr(stats[0]) if stats else None, stat_sq=_ptr(stats[1]) if stats else None,
+             conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+    return y
+
+
+def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride: int, pad: int,
+               residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+               accumulate: bool = False) -> torch.Tensor:
+    """dx (Nb,H,W,Cin) = conv-transpose of dy (Nb,Ho,Wo,Cout) with w (Cout,R,S,Cin) [+ residual]."""
+    Nb, Ho, Wo, Cout = dy.shape
+    _, R, S, Cin = w.shape
+    H, W = in_hw
+    assert dy.is_contiguous() and w.is_contiguous()
+    dx = out if out is not None else empty(Nb, H, W, Cin, device=dy.device)
+    K = R * S * Cout
+    gemm_raw(OP_CONV_DGRAD, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, 0, 0, Cin,
+             residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
+             conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+    return dx
+
+
+def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int, pad: int, splitk: int = 0) -> None:
+    """dw (Cout,R,S,Cin) += sum over output pixels of dy (x) gathered x (accumulates, fp32 atomics when split)."""
+    Nb, Ho, Wo, Cout = dy.shape
+    _, H, W, Cin = x.shape
+    _, R, S, _ = dw.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
+    K = Nb * Ho * Wo
+    N = R * S * Cin
+    if splitk <= 0:
+        tiles = ((Cout + 127) // 128) * ((N + 127) // 128)
+        splitk = max(1, min(64, 768 // max(tiles, 1), K // 128))
+    if splitk > 1:
+        gemm_raw(OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, splitk=splitk,
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+    else:
+        gemm_raw(OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, accumulate=True,
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+
+
+# ----------------------------------------------------------------------------- BatchNorm pieces
+def bn_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps):
+    C = gamma.numel()
+    co = empty(4, C, device=gamma.device)  # scale, shift, mean, invstd
+    check(_lib.lib().ick_bn_finalize(ssum.data_ptr(), ssq.data_ptr(), float(count), gamma.data_ptr(), beta.data_ptr(),
+                                     _ptr(rmean), _ptr(rvar), momentum, eps, co[0].data_ptr(), co[1].data_ptr(),
+                                     co[2].data_ptr(), co[3].data_ptr(), C, _st()), "ick_bn_finalize")
+    return co
+
+
+def bn_eval_coeffs(gamma, beta, rmean, rvar, eps):
+    C = gamma.numel()
+    co = empty(2, C, device=gamma.device)
+    check(_lib.lib().ick_bn_eval_coeffs(gamma.data_ptr(), beta.data_ptr(), rmean.data_ptr(), rvar.data_ptr(), eps,
+                                        co[0].data_ptr(), co[1].data_ptr(), C, _st()), "ick_bn_eval_coeffs")
+    return co
+
+
+def scale_shift_act(x, scale, shift, residual, relu: bool, out=None):
+    C = x.shape[-1]
+    y = out if out is not None else torch.empty_like(x)
+    check(_lib.lib().ick_scale_shift_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(residual), y.data_ptr(),
+                                         x.numel() // C, C, int(relu), _st()), "ick_scale_shift_act")
+    return y
+
+
+def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batch_stats: bool = True):
+    """Backward through [relu](bn(x)[+res]).  dy: grad wrt the block output; y_mask: that output (relu mask) or None.
+    Accumulates dgamma/dbeta (+=); returns (dx, g) with g = masked dy (gradient of the residual branch) if want_g."""
+    C = x.shape[-1]
+    M = x.numel() // C
+    sums = zeros(2, C, device=x.device)
+    check(_lib.lib().ick_bn_bwd_reduce(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                       sums[0].data_ptr(), sums[1].data_ptr(), M, C, _st()), "ick_bn_bwd_reduce")
+    dx = torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    check(_lib.lib().ick_bn_bwd_apply(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                      gamma.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), dx.data_ptr(), _ptr(g),
+                                      M, C, int(batch_stats), _st()), "ick_bn_bwd_apply")
+    if dgamma is not None:
+        add(dgamma, sums[1], out=dgamma)   # dgamma += sum(g*xhat)
+        add(dbeta, sums[0], out=dbeta)     # dbeta  += sum(g)
+    return dx, g
+
+
+def maxpool3x3s2(x):
+    Nb, H, W, C = x.shape
+    Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    y = empty(Nb, Ho, Wo, C, device=x.device)
+    check(_lib.lib().ick_maxpool3x3s2(x.data_ptr(), y.data_ptr(), Nb, H, W, C, _st()), "ick_maxpool3x3s2")
+    return y
+
+
+def nchw3_to_nhwc4(images):
+    B, C, H, W = images.shape
+    assert C == 3 and images.is_contiguous()
+    y = empty(B, H, W, 4, device=images.device)
+    check(_lib.lib().ick_nchw3_to_nhwc4(images.data_ptr(), y.data_ptr(), B, H, W, _st()), "ick_nchw3_to_nhwc4")
+    return y
+
+
+# ----------------------------------------------------------------------------- ViT helpers / embedding / pooling
+def patchify16(images):
+    B, C, H, W = images.shape
+    assert C == 3 and H == W and images.is_contiguous()
+    G = H // 16
+    y = empty(B * G * G, 768, device=images.device)
+    check(_lib.lib().ick_patchify16(images.data_ptr(), y.data_ptr(), B, H, _st()), "ick_patchify16")
+    return y
+
+
+def vit_assemble(patch, cls, pos, B, Ntok, D):
+    x = empty(B, Ntok, D, device=patch.device)
+    check(_lib.lib().ick_vit_assemble(patch.data_ptr(), cls.data_ptr(), pos.data_ptr(), x.data_ptr(), B, Ntok, D, _st()),
+          "ick_vit_assemble")
+    return x
+
+
+def embedding_fwd(ids: torch.Tensor, table: torch.Tensor, pe: Optional[torch.Tensor] = None, per_pos: int = 1):
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and ids.is_cuda
+    D = table.shape[1]
+    out = empty(*ids.shape, D, device=table.device)
+    check(_lib.lib().ick_embedding_fwd(ids.data_ptr(), table.data_ptr(), _ptr(pe), out.data_ptr(), ids.numel(), D, per_pos,
+                                       _st()), "ick_embedding_fwd")
+    return out
+
+
+def embedding_bwd(ids, dout, dtable):
+    D = dtable.shape[1]
+    check(_lib.lib().ick_embedding_bwd(ids.data_ptr(), dout.data_ptr(), dtable.data_ptr(), ids.numel(), D, _st()),
+          "ick_embedding_bwd")
+
+
+def token_pool_fwd(x, Lo):
+    B, L, D = x.shape
+    y = empty(B, Lo, D, device=x.device)
+    check(_lib.lib().ick_token_pool_fwd(x.data_ptr(), y.data_ptr(), B, L, Lo, D, _st()), "ick_token_pool_fwd")
+    return y
+
+
+def token_pool_bwd(dy, L):
+    B, Lo, D = dy.shape
+    dx = empty(B, L, D, device=dy.device)
+    check(_lib.lib().ick_token_pool_bwd(dy.data_ptr(), dx.data_ptr(), B, L, Lo, D, _st()), "ick_token_pool_bwd")
+    return dx

@@ -1,0 +1,117 @@
+/*
+ * ick.h — C ABI of libick.so, the MI355X (gfx950) kernel library behind the
+ * image-captioning knowledge-distillation hot path.
+ *
+ * The reference (VeeraKarthick609/ImageCaptioner) has NO native/FFI layer: its
+ * boundary is the Python nn.Module surface.  This header is the
+ * build-side C boundary underneath that surface; every entry names the reference
+ * computation it replaces (file:line into /root/reference).  A maintainer of the
+ * reference binds it with ctypes exactly as imagecaptioner_amd/_lib.py does
+ * (see INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain pointers + sizes only; all pointers are DEVICE pointers (HBM) unless named host_*
+ *   - every launcher takes the HIP stream as `void* stream` (hipStream_t); nothing syncs,
+ *     nothing allocates: callers own all outputs and workspaces
+ *   - return 0 on success, <0 for a rejected argument, >0 = hipError_t of the launch;
+ *     ick_last_error() returns a thread-local message for the last non-zero return
+ *   - tensors are fp32; activations of the CNN are NHWC ("channels_last"), conv weights
+ *     are [Cout][R][S][Cin] (the physical layout of a channels_last OIHW torch tensor)
+ */
+#ifndef ICK_H
+#define ICK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICK_ABI_VERSION 1
+
+const char* ick_last_error(void);
+int ick_abi_version(void);
+
+/* ------------------------------------------------------------------ implicit GEMM (fp32 MFMA)
+ * C[z][m][n] = act(alpha * sum_k A(m,k) * B(n,k) + bias[n]) + residual[m][n]
+ * One kernel family (v_mfma_f32_32x32x2_f32, LDS-tiled) serves every dense contraction of
+ * the path: nn.Linear fwd/bwd (student_model.py:37-42,91-96,138-139,151-156; teacher_model.py:50,60-71;
+ * distillation_utils.py:217-222), attention QK^T / PV batched over (batch, head)
+ * (student_model.py:83-88, teacher_model.py:60-67, timm ViT blocks), and ResNet-50 convolutions
+ * fwd / dgrad / wgrad as implicit GEMM over NHWC (student_model.py:16-20,57).
+ */
+enum {
+  ICK_OP_NT = 0,        /* A [M][K] (lda), B [N][K] (ldb)             : y = x W^T               */
+  ICK_OP_NN = 1,        /* A [M][K] (lda), B [K][N] (ldb)             : dx = dy W               */
+  ICK_OP_TN = 2,        /* A [K][M] (lda), B [K][N] (ldb)             : dW = dy^T x             */
+  ICK_OP_CONV_FWD = 3,  /* A = im2col(X NHWC), B = W [Cout][R*S*Cin]                             */
+  ICK_OP_CONV_FWD_C4 = 4,/* same, Cin == 4 (padded RGB stem), K = R*S*4                          */
+  ICK_OP_CONV_DGRAD = 5,/* A = gather(dY NHWC), B = W as [k=(tap,co)][n=ci]  -> dX NHWC          */
+  ICK_OP_CONV_WGRAD = 6 /* A = dY as [K=B*Ho*Wo][M=Cout], B = gather(X) [K][N=(tap,ci)] -> dW    */
+};
+enum { ICK_ACT_NONE = 0, ICK_ACT_RELU = 1, ICK_ACT_GELU = 2, ICK_ACT_TANH = 3 };
+
+typedef struct IckGemm {
+  const float* A; const float* B; float* C;
+  const float* bias;       /* [N] or NULL */
+  const float* residual;   /* [M][ldr] or NULL, same batch strides as C */
+  float* stat_sum;         /* [N] or NULL: += column sums of the raw (pre-activation) product (BatchNorm batch stats) */
+  float* stat_sq;          /* [N] or NULL: += column sums of squares */
+  int32_t op, act;
+  int32_t M, N, K;
+  int64_t lda, ldb, ldc, ldr;
+  int32_t batch_outer, batch_inner;             /* grid.z = outer*inner (1,1 for plain) */
+  int64_t sAo, sAi, sBo, sBi, sCo, sCi;         /* element strides per outer / inner batch index */
+  int32_t splitk;                               /* >1: K split over grid.z, C accumulated with fp32 atomics (C pre-zeroed or holding the value to add to) */
+  int32_t accumulate;                           /* 1: C += result (non-atomic, splitk==1) */
+  float alpha;
+  /* convolution geometry (ICK_OP_CONV_*): X [Nb][H][W][Cin], Y [Nb][Ho][Wo][Cout] */
+  int32_t Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+} IckGemm;
+
+int ick_gemm_f32(const IckGemm* desc, void* stream);
+
+/* ------------------------------------------------------------------ layout transforms
+ * images arrive as the reference hands them over: (B,3,224,224) fp32 NCHW (train_student_kd.py:259). */
+int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stream);      /* -> (B,H,W,4), 4th channel 0 */
+int ick_patchify16(const float* x, float* y, int B, int HW, void* stream);                /* -> [B*(HW/16)^2][768], k=(c,py,px): timm PatchEmbed as a GEMM */
+int ick_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int Ntok, int D, void* stream); /* cls token + pos_embed (timm forward_features) */
+
+/* ------------------------------------------------------------------ BatchNorm2d over NHWC rows [M = B*H*W][C]
+ * nn.BatchNorm2d inside torchvision resnet50 (student_model.py:16-20,57); train mode = batch statistics + running-stat
+ * update, also for the "frozen" stem.  Batch sums come from the conv epilogue (IckGemm.stat_*). */
+int ick_bn_finalize(const float* sum, const float* sq, float count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
+int ick_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
+                       float* scale, float* shift, int C, void* stream);
+int ick_scale_shift_act(const float* x, const float* scale, const float* shift, const float* residual, float* y,
+                        int64_t M, int C, int relu, void* stream);                          /* y = [relu](x*scale+shift [+ residual]) */
+int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                      float* sum_g, float* sum_gx, int64_t M, int C, void* stream);          /* += sum(g), sum(g*xhat); g = dy*(y>0) if y */
+int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                     const float* gamma, const float* sum_g, const float* sum_gx, float* dx, float* g_out,
+                     int64_t M, int C, int use_batch_stats, void* stream);
+int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream); /* nn.MaxPool2d(3,2,1), NHWC */
+
+/* ------------------------------------------------------------------ LayerNorm / softmax / small utilities
+ * nn.LayerNorm (student_model.py:41,99-100; teacher_model.py:70; timm blocks eps=1e-6; distillation_utils.py:221) */
+int ick_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                      int64_t rows, int D, float eps, void* stream);
+int ick_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                      float* dx, float* dgamma, float* dbeta, int64_t rows, int D, void* stream); /* dgamma/dbeta accumulated (+=) */
+int ick_softmax_rows(float* s, int64_t rows, int L, int ld, float scale, int causal, int Lq, void* stream);   /* in place: softmax(scale*s) */
+int ick_softmax_bwd_rows(float* dp, const float* p, int64_t rows, int L, int ld, float scale, void* stream);  /* in place on dp */
+int ick_colsum(const float* x, float* out, int64_t M, int N, int64_t ld, void* stream);         /* out[n] += sum_m x[m][n] (bias grads) */
+int ick_relu_bwd(const float* dy, const float* y, float* dx, int64_t n, void* stream);
+int ick_add(const float* a, const float* b, float* y, int64_t n, void* stream);
+int ick_embedding_fwd(const int64_t* ids, const float* table, const float* pe, float* out, int64_t n, int D, int per_pos,
+                      void* stream);                                                      /* nn.Embedding (+ sinusoid PE rows, teacher_model.py:25-27) */
+int ick_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int D, void* stream);
+int ick_token_pool_fwd(const float* x, float* y, int B, int L, int Lo, int D, void* stream); /* nn.AdaptiveAvgPool1d over tokens (distillation_utils.py:229,246-250) */
+int ick_token_pool_bwd(const float* dy, float* dx, int B, int L, int Lo, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICK_H */

@@ -1,0 +1,142 @@
+"""GPU parity of the fp32 MFMA implicit-GEMM family (csrc/igemm_f32.hip) through the C ABI,
+against float64 CPU references built from torch primitives.  Tolerance: 2e-5 relative to the
+output scale (exact-fp32 MFMA = fmaf chain; the reference path is fp32 too, so only summation
+order differs)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from imagecaptioner_amd import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (128, 128, 32), (197, 5000, 72), (960, 256, 512), (3136, 256, 2048),
+                                   (33, 7, 20), (1, 1, 4), (300, 384, 1536)])
+def test_linear_fwd_bwd(ops, M, N, K):
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    xd, wd, bd, rd = (t.cuda() for t in (x, w, b, r))
+    for act, fn in ((0, lambda v: v), (1, torch.relu), (2, F.gelu), (3, torch.tanh)):
+        y = ops.linear_fwd(xd, wd, bd, act=act, residual=rd)
+        ref = fn(x.double() @ w.double().T + b.double()) + r.double()
+        assert rel_err(y, ref) < TOL, f"fwd act={act}"
+    dy = rnd(M, N, seed=5)
+    dyd = dy.cuda()
+    if K % 4 == 0 and N % 4 == 0:
+        dx = ops.linear_bwd_data(dyd, wd)
+        assert rel_err(dx, dy.double() @ w.double()) < TOL
+        for sk in (1, 3):
+            dw = torch.ones(N, K, device="cuda")
+            ops.linear_bwd_weight(dyd, xd, dw, splitk=sk)
+            assert rel_err(dw, 1.0 + dy.double().T @ x.double()) < TOL, f"wgrad splitk={sk}"
+        db = torch.zeros(N, device="cuda")
+        ops.colsum_into(dyd, db)
+        assert rel_err(db, dy.double().sum(0)) < TOL
+
+
+def test_mfma_layout_asymmetric(ops):
+    """A = I against an asymmetric B: catches a transposed C write (guide §3)."""
+    n = 128
+    A = torch.eye(n)
+    Bm = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 997.0   # B[i][j] != B[j][i]
+    y = ops.linear_fwd(A.cuda(), Bm.cuda())         # y = A @ B^T = B^T
+    assert torch.equal(y.cpu(), Bm.T.contiguous())
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,d,causal", [(2, 6, 197, 197, 64, False), (3, 4, 49, 49, 64, False),
+                                                (2, 8, 15, 15, 64, True), (2, 8, 15, 197, 64, False)])
+def test_attention_core(ops, B, H, Lq, Lk, d, causal):
+    E = H * d
+    q = rnd(B * Lq, 3 * E, seed=1)
+    kv = rnd(B * Lk, 3 * E, seed=2) if Lk != Lq else q
+    qd, kvd = q.cuda(), kv.cuda()
+    O, P = ops.attention_fwd(qd, 0, 3 * E, kvd, E, 3 * E, kvd, 2 * E, 3 * E, B, H, Lq, Lk, d, causal)
+    qq = q[:, :E].double().view(B, Lq, H, d).transpose(1, 2).requires_grad_(True)
+    kk = kv[:, E:2 * E].double().view(B, Lk, H, d).transpose(1, 2).requires_grad_(True)
+    vv = kv[:, 2 * E:].double().view(B, Lk, H, d).transpose(1, 2).requires_grad_(True)
+    s = qq @ kk.transpose(-1, -2) / math.sqrt(d)
+    if causal:
+        s = s.masked_fill(torch.ones(Lq, Lk, dtype=torch.bool).triu(1), float("-inf"))
+    p = torch.softmax(s, -1)
+    o = (p @ vv).transpose(1, 2).reshape(B * Lq, E)
+    assert rel_err(P[..., :Lk], p) < TOL
+    assert P[..., Lk:].abs().max().item() == 0 if P.shape[-1] > Lk else True
+    assert rel_err(O, o) < TOL
+    dO = rnd(B * Lq, E, seed=3)
+    (o * dO.double()).sum().backward()
+    dq = torch.zeros(B * Lq, 3 * E, device="cuda")
+    dkv = torch.zeros(B * Lk, 3 * E, device="cuda") if Lk != Lq else dq
+    ops.attention_bwd(dO.cuda(), P, qd, 0, 3 * E, kvd, E, 3 * E, kvd, 2 * E, 3 * E,
+                      dq, 0, 3 * E, dkv, E, 3 * E, dkv, 2 * E, 3 * E, B, H, Lq, Lk, d)
+    assert rel_err(dq[:, :E], qq.grad.transpose(1, 2).reshape(B * Lq, E)) < 5e-5
+    assert rel_err(dkv[:, E:2 * E], kk.grad.transpose(1, 2).reshape(B * Lk, E)) < 5e-5
+    assert rel_err(dkv[:, 2 * E:], vv.grad.transpose(1, 2).reshape(B * Lk, E)) < 5e-5
+
+
+CONVS = [  # (Nb, H, W, Cin, Cout, R, stride, pad) — every distinct ResNet-50 conv geometry at reduced batch
+    (2, 56, 56, 64, 64, 1, 1, 0), (2, 56, 56, 64, 64, 3, 1, 1), (2, 56, 56, 64, 256, 1, 1, 0),
+    (2, 56, 56, 256, 128, 1, 1, 0), (2, 56, 56, 128, 128, 3, 2, 1), (2, 56, 56, 256, 512, 1, 2, 0),
+    (2, 28, 28, 512, 256, 1, 1, 0), (2, 28, 28, 256, 256, 3, 2, 1), (2, 14, 14, 256, 256, 3, 1, 1),
+    (2, 14, 14, 1024, 2048, 1, 2, 0), (3, 14, 14, 512, 512, 3, 2, 1), (3, 7, 7, 512, 512, 3, 1, 1),
+    (3, 7, 7, 2048, 512, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("Nb,H,W,Cin,Cout,R,stride,pad", CONVS)
+def test_conv_fwd_dgrad_wgrad(ops, Nb, H, W, Cin, Cout, R, stride, pad):
+    x = rnd(Nb, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, R, R, seed=2, scale=1.0 / math.sqrt(Cin * R * R))
+    xd = x.cuda().permute(0, 2, 3, 1).contiguous()          # NHWC
+    wd = w.cuda().permute(0, 2, 3, 1).contiguous()          # (Cout,R,S,Cin)
+    stats = torch.zeros(2, Cout, device="cuda")
+    y = ops.conv_fwd(xd, wd, stride, pad, stats=(stats[0], stats[1]))
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL
+    assert rel_err(stats[0], ref.sum((0, 2, 3))) < 1e-4 * max(1.0, ref.abs().sum((0, 2, 3)).max().item() / ref.sum((0, 2, 3)).abs().max().item())
+    assert rel_err(stats[1], (ref * ref).sum((0, 2, 3))) < 1e-4
+    dy = rnd(*ref.shape, seed=3)
+    dyd = dy.cuda().permute(0, 2, 3, 1).contiguous()
+    res = rnd(Nb, H, W, Cin, seed=4).cuda()
+    dx = ops.conv_dgrad(dyd, wd, (H, W), stride, pad, residual=res)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), stride, pad) + res.cpu().double().permute(0, 3, 1, 2)
+    assert rel_err(dx.permute(0, 3, 1, 2), dx_ref) < TOL
+    dw_ref = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), stride, pad)
+    for sk in (1, 0):
+        dw = torch.zeros_like(wd)
+        ops.conv_wgrad(dyd, xd, dw, stride, pad, splitk=sk)
+        assert rel_err(dw.permute(0, 3, 1, 2), dw_ref) < 5e-5, f"wgrad splitk={sk}"
+
+
+def test_conv_stem_c4(ops):
+    x = rnd(2, 3, 224, 224, seed=1)
+    w = rnd(64, 3, 7, 7, seed=2, scale=0.1)
+    x4 = ops.nchw3_to_nhwc4(x.cuda())
+    assert torch.equal(x4[..., :3].cpu(), x.permute(0, 2, 3, 1)) and x4[..., 3].abs().max().item() == 0
+    w4 = torch.zeros(64, 7, 7, 4, device="cuda")
+    w4[..., :3] = w.cuda().permute(0, 2, 3, 1)
+    stats = torch.zeros(2, 64, device="cuda")
+    y = ops.conv_fwd(x4, w4, 2, 3, stats=(stats[0], stats[1]))
+    ref = F.conv2d(x.double(), w.double(), None, 2, 3)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL
+    assert rel_err(stats[1], (ref * ref).sum((0, 2, 3))) < 1e-4
+    mp = ops.maxpool3x3s2(y)
+    assert torch.equal(mp.permute(0, 3, 1, 2).cpu(), F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 3, 2, 1))
