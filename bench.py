@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py — images/sec of the KD train step (BASELINE.json metric) on N MI355X of one node.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): BASELINE.json configs[2] "Full KD step" (cfg3 of SURVEY.md §8(d)) — ViT-S/16 +
+4-layer decoder teacher forward (fp32, no grad), ResNet50+refinement+2-layer-LSTM student forward in TRAIN mode
+(BatchNorm batch statistics, reference dropout rates), feature projector, fused KD loss (alpha .7 / beta .2 /
+gamma .1 / T 4), backward through decoder / refinement / projection / layer4 / layer3, gradient all-reduce
+(N>1, RCCL), clip_grad_norm_(1.0) and AdamW — batch 64 per GPU, V=5000, T=15, synthetic 224x224 inputs resident in
+HBM, key-seeded random-init weights (no datasets/checkpoints offline).  One "step" = one optimizer step on one
+batch per rank (accumulation_steps=1: strictly more work per image than the reference's accumulate-2 loop).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE = 28.4          # algorithmic, SURVEY.md §8(d): teacher 9.80 + student fwd+loss+bwd 18.61 (2 FLOP per MAC)
+PEAK_F32_MFMA_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+BATCH = 64
+VOCAB, T1 = 5000, 16
+
+
+def cpu_baseline(batch: int = 16):
+    """The oracle (CPU restatement, plain PyTorch fp32) timed on this box's host cores on a bounded sample of the
+    same workload: teacher fwd + student fwd (train-mode BN, dropout off) + KD loss + backward, single ViT pass."""
+    from oracle import restatement as R
+    from imagecaptioner_amd.utils.seeded_init import seeded_state_dict, synthetic_batch
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    trainable = lambda k: not any(k.startswith(f"encoder.resnet.{i}.") for i in (0, 1, 4, 5)) and "running_" not in k
+    mk = lambda sd: {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and trainable(k)) else v.clone())
+                     for k, v in sd.items()}
+    ssd = mk(seeded_state_dict(R.student_state_shapes(VOCAB, 256, 512, 2, True), seed=0))
+    tsd = seeded_state_dict(R.teacher_state_shapes(VOCAB, 512, 4), seed=1)
+    psd = mk(seeded_state_dict(R.projector_state_shapes(512, 256), seed=2))
+    images, caps = synthetic_batch(batch, VOCAB, T1, seed=1234)
+    run = lambda: R.kd_forward_backward(ssd, tsd, psd, images, caps, hidden=512, layers=2, refine=True, t_heads=8, t_layers=4)
+    run()                                   # warm-up (thread pools, allocator)
+    steps, t0 = 0, time.perf_counter()
+    while steps < 2 or (time.perf_counter() - t0 < 10.0 and steps < 6):
+        for v in list(ssd.values()) + list(psd.values()):
+            v.grad = None
+        run()
+        steps += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} steps of batch {batch} (teacher fwd + student fwd + KD loss + bwd, fp32, single ViT pass, "
+                      f"no optimizer), torch {torch.__version__} CPU eager"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE: 64)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+
+    student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev)    # identical init on every rank
+    trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
+                        use_graph=not args.no_graph)
+    images, caps = synthetic_batch(args.batch, VOCAB, T1, seed=1234, rank=rank)     # rank-specific shard of the global batch
+    log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
+    log("models built; first step (hipGraph capture) ...")
+    trainer.train_step(images.to(dev), caps.to(dev))                                # inputs resident in HBM from here on
+    torch.cuda.synchronize()
+    log("captured; warm-up ...")
+    for _ in range(max(0, args.warmup - 1)):
+        trainer.train_step()
+    torch.cuda.synchronize()
+    log(f"timing {args.steps} steps ...")
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        trainer.train_step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)                      # HIP events on the stream every kernel of the step runs on
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = trainer.loss_dict()
+    if rank == 0:
+        ips = world * args.batch * args.steps / dt
+        step_ms_dev = dev_ms / args.steps
+        achieved = GFLOP_PER_IMAGE * args.batch / step_ms_dev            # GFLOP / ms = TFLOP/s, this rank's GPU
+        out = {
+            "metric": "images/sec KD train step (teacher+student fwd + KD loss + bwd)", "value": round(ips, 2),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "cfg3 full KD step: vit_small_patch16_224 teacher (embed 512/8 heads/4 layers) + "
+                                   "ResNet50-LSTM student (256/512/2-layer, refinement on), alpha=0.7 beta=0.2 gamma=0.1 T=4, "
+                                   "V=5000, T=15, 224x224, clip 1.0 + AdamW every step",
+                       "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "hipgraph": not args.no_graph, "final_loss": round(loss["total_loss"], 5)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                         "note": "whole step: 28.4 algorithmic GFLOP/image (SURVEY 8d) x batch / device time per step "
+                                 "(HIP events on the launch stream); denominator = fp32 MFMA peak (exact-fp32 path)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del trainer, student, teacher, projectors
+            torch.cuda.empty_cache()
+            log(f"GPU: {ips:.1f} images/s; timing the CPU baseline on a bounded sample ...")
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

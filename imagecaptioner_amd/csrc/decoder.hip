@@ -1,0 +1,220 @@
+// decoder.hip — per-time-step kernels of the student's LSTM + spatial-attention decoder
+// (reference: LSTMDecoder.attention_mechanism /root/reference/src/student_model.py:173-203 and the loop body
+// :232-251).  The decoder is recast so that everything time-invariant is hoisted out of the loop:
+//   W_a [h ; f_j] = W_h h + (W_f f_j + b_a)   -> Uf = feats W_f^T + b_a is ONE GEMM per image batch,
+// and the per-step work is GEMV-sized contractions (igemm_f32) plus these HBM/LDS-bound wavefront kernels:
+//   attn_step_fwd : scores_j = sum_e tanh(Uf[b,j,e] + hW[b,e]); w = softmax_j; ctx = sum_j w_j f_j
+//   attn_step_bwd : the exact adjoint (recomputes tanh from Uf + hW; accumulates dUf, dfeats in place)
+//   lstm_cell_fwd / lstm_cell_bwd : gate nonlinearities + state update / adjoint (gate order i,f,g,o)
+//   argmax_rows   : greedy token selection (first maximum, like torch.argmax)
+#include "ick_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// one workgroup per image b; L positions (49), E features
+__global__ __launch_bounds__(NT) void attn_step_fwd_kernel(const float* __restrict__ Uf, const float* __restrict__ hW,
+                                                          const float* __restrict__ feats, float* __restrict__ w_out,
+                                                          float* __restrict__ ctx, int L, int E) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [L] scores/weights + [E] hW row
+  float* sc = sh;
+  float* hrow = sh + ((L + 3) & ~3);
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* U = Uf + (long)b * L * E;
+  const float* F = feats + (long)b * L * E;
+  for (int e = tid; e < E; e += NT) hrow[e] = hW[(long)b * E + e];
+  __syncthreads();
+  for (int j = wave; j < L; j += NT / 64) {
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += tanhf(U[(long)j * E + e] + hrow[e]);
+    s = wave_sum(s);
+    if (lane == 0) sc[j] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {  // softmax over L <= 64*k positions
+    float mx = -INFINITY;
+    for (int j = lane; j < L; j += 64) mx = fmaxf(mx, sc[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int j = lane; j < L; j += 64) sum += expf(sc[j] - mx);
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+    for (int j = lane; j < L; j += 64) {
+      const float w = expf(sc[j] - mx) * inv;
+      sc[j] = w;
+      w_out[(long)b * L + j] = w;
+    }
+  }
+  __syncthreads();
+  for (int e = tid; e < E; e += NT) {
+    float a = 0.f;
+    for (int j = 0; j < L; ++j) a += sc[j] * F[(long)j * E + e];
+    ctx[(long)b * E + e] = a;
+  }
+}
+
+// adjoint of attn_step_fwd for one step: dUf += dpre, dfeats += w (x) dctx, dhW = sum_j dpre
+__global__ __launch_bounds__(NT) void attn_step_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ w,
+                                                          const float* __restrict__ Uf, const float* __restrict__ hW,
+                                                          const float* __restrict__ feats, float* __restrict__ dUf,
+                                                          float* __restrict__ dfeats, float* __restrict__ dhW, int L, int E) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [L] ds, [L] w, [E] dctx
+  const int Lp = (L + 3) & ~3;
+  float* ds = sh;
+  float* wl = sh + Lp;
+  float* dc = sh + 2 * Lp;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long base = (long)b * L * E;
+  for (int e = tid; e < E; e += NT) dc[e] = dctx[(long)b * E + e];
+  for (int j = tid; j < L; j += NT) wl[j] = w[(long)b * L + j];
+  __syncthreads();
+  for (int j = wave; j < L; j += NT / 64) {  // dw_j = <dctx, f_j>
+    float s = 0.f;
+    for (int e = lane; e < E; e += 64) s += dc[e] * feats[base + (long)j * E + e];
+    s = wave_sum(s);
+    if (lane == 0) ds[j] = s;
+  }
+  __syncthreads();
+  if (wave == 0) {  // softmax adjoint: ds_j = w_j (dw_j - sum_i w_i dw_i)
+    float d = 0.f;
+    for (int j = lane; j < L; j += 64) d += wl[j] * ds[j];
+    d = wave_sum(d);
+    for (int j = lane; j < L; j += 64) ds[j] = wl[j] * (ds[j] - d);
+  }
+  __syncthreads();
+  for (int e = tid; e < E; e += NT) {
+    const float h = hW[(long)b * E + e], dce = dc[e];
+    float acc = 0.f;
+    for (int j = 0; j < L; ++j) {
+      const long o = base + (long)j * E + e;
+      // d tanh = sech^2 = 4 e^{-2|x|} / (1 + e^{-2|x|})^2 : relative accuracy also where tanh saturates
+      // (1 - tanh^2 loses all digits there)
+      const float ex = expf(-2.f * fabsf(Uf[o] + h));
+      const float dp = ds[j] * (4.f * ex / ((1.f + ex) * (1.f + ex)));
+      dUf[o] += dp;
+      dfeats[o] += wl[j] * dce;
+      acc += dp;
+    }
+    dhW[(long)b * E + e] = acc;
+  }
+}
+
+// gates G (B,4H) = x W_ih^T + h W_hh^T (raw sums from the GEMMs) + b_ih + b_hh ; order i,f,g,o
+__global__ void lstm_cell_fwd_kernel(const float* __restrict__ G, const float* __restrict__ bih, const float* __restrict__ bhh,
+                                     const float* __restrict__ c_prev, float* __restrict__ gates, float* __restrict__ c_out,
+                                     float* __restrict__ h_out, int B, int H) {
+  const long total = (long)B * H;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / H; const int h = (int)(i - b * H);
+    const float* g = G + b * 4 * H;
+    const float gi = sigmoidf_(g[h] + bih[h] + bhh[h]);
+    const float gf = sigmoidf_(g[H + h] + bih[H + h] + bhh[H + h]);
+    const float gg = tanhf(g[2 * H + h] + bih[2 * H + h] + bhh[2 * H + h]);
+    const float go = sigmoidf_(g[3 * H + h] + bih[3 * H + h] + bhh[3 * H + h]);
+    const float c = gf * (c_prev ? c_prev[i] : 0.f) + gi * gg;
+    c_out[i] = c;
+    h_out[i] = go * tanhf(c);
+    if (gates) {
+      float* s = gates + b * 4 * H;
+      s[h] = gi; s[H + h] = gf; s[2 * H + h] = gg; s[3 * H + h] = go;
+    }
+  }
+}
+
+// dh = dh_a (+ dh_b); dc = dc_in + dh*o*(1-tanh(c)^2); writes dG (pre-activation) and dc_prev (may alias dc_in)
+__global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh_a, const float* __restrict__ dh_b,
+                                     const float* dc_in, const float* __restrict__ gates, const float* __restrict__ c,
+                                     const float* __restrict__ c_prev, float* __restrict__ dG, float* dc_prev, int B, int H) {
+  const long total = (long)B * H;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / H; const int h = (int)(i - b * H);
+    const float* s = gates + b * 4 * H;
+    const float gi = s[h], gf = s[H + h], gg = s[2 * H + h], go = s[3 * H + h];
+    float dh = dh_a[i];
+    if (dh_b) dh += dh_b[i];
+    const float tc = tanhf(c[i]);
+    const float dc = (dc_in ? dc_in[i] : 0.f) + dh * go * (1.f - tc * tc);
+    float* d = dG + b * 4 * H;
+    d[h] = dc * gg * gi * (1.f - gi);
+    d[H + h] = dc * (c_prev ? c_prev[i] : 0.f) * gf * (1.f - gf);
+    d[2 * H + h] = dc * gi * (1.f - gg * gg);
+    d[3 * H + h] = dh * tc * go * (1.f - go);
+    dc_prev[i] = dc * gf;
+  }
+}
+
+// ids[r] = first index of the maximum of logits[r][0..V) scaled by inv_temp (one wave per row)
+__global__ void argmax_rows_kernel(const float* __restrict__ x, long* __restrict__ ids, long rows, int V, long ld) {
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  for (long r = blockIdx.x * (long)wpb + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * wpb) {
+    const float* xr = x + r * ld;
+    float best = -INFINITY; int bi = V;
+    for (int i = lane; i < V; i += 64) {
+      const float v = xr[i];
+      if (v > best) { best = v; bi = i; }   // strict > keeps the first maximum within a lane
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) ids[r] = bi;
+  }
+}
+
+}  // namespace
+
+#define ST static_cast<hipStream_t>(stream)
+
+extern "C" {
+
+int ick_attn_step_fwd(const float* Uf, const float* hW, const float* feats, float* w_out, float* ctx, int B, int L, int E,
+                      void* stream) {
+  ICK_REQUIRE(Uf && hW && feats && w_out && ctx && B > 0 && L > 0 && E > 0, "ick_attn_step_fwd: bad arguments");
+  const size_t sh = (((L + 3) & ~3) + E) * sizeof(float);
+  ICK_LAUNCH(attn_step_fwd_kernel, dim3(B), dim3(NT), sh, ST, Uf, hW, feats, w_out, ctx, L, E);
+  return ick::launch_status("attn_step_fwd");
+}
+
+int ick_attn_step_bwd(const float* dctx, const float* w, const float* Uf, const float* hW, const float* feats, float* dUf,
+                      float* dfeats, float* dhW, int B, int L, int E, void* stream) {
+  ICK_REQUIRE(dctx && w && Uf && hW && feats && dUf && dfeats && dhW && B > 0 && L > 0 && E > 0,
+              "ick_attn_step_bwd: bad arguments");
+  const size_t sh = (2 * ((L + 3) & ~3) + E) * sizeof(float);
+  ICK_LAUNCH(attn_step_bwd_kernel, dim3(B), dim3(NT), sh, ST, dctx, w, Uf, hW, feats, dUf, dfeats, dhW, L, E);
+  return ick::launch_status("attn_step_bwd");
+}
+
+int ick_lstm_cell_fwd(const float* G, const float* b_ih, const float* b_hh, const float* c_prev, float* gates, float* c_out,
+                      float* h_out, int B, int H, void* stream) {
+  ICK_REQUIRE(G && b_ih && b_hh && c_out && h_out && B > 0 && H > 0, "ick_lstm_cell_fwd: bad arguments");
+  long g = ((long)B * H + NT - 1) / NT; if (g > 2048) g = 2048;
+  ICK_LAUNCH(lstm_cell_fwd_kernel, dim3((int)g), dim3(NT), 0, ST, G, b_ih, b_hh, c_prev, gates, c_out, h_out, B, H);
+  return ick::launch_status("lstm_cell_fwd");
+}
+
+int ick_lstm_cell_bwd(const float* dh_a, const float* dh_b, const float* dc_in, const float* gates, const float* c,
+                      const float* c_prev, float* dG, float* dc_prev, int B, int H, void* stream) {
+  ICK_REQUIRE(dh_a && gates && c && dG && dc_prev && B > 0 && H > 0, "ick_lstm_cell_bwd: bad arguments");
+  long g = ((long)B * H + NT - 1) / NT; if (g > 2048) g = 2048;
+  ICK_LAUNCH(lstm_cell_bwd_kernel, dim3((int)g), dim3(NT), 0, ST, dh_a, dh_b, dc_in, gates, c, c_prev, dG, dc_prev, B, H);
+  return ick::launch_status("lstm_cell_bwd");
+}
+
+int ick_argmax_rows(const float* x, int64_t* ids, int64_t rows, int V, int64_t ld, void* stream) {
+  ICK_REQUIRE(x && ids && rows > 0 && V > 0 && ld >= V, "ick_argmax_rows: bad arguments");
+  long g = (rows + 3) / 4; if (g > 2048) g = 2048;
+  ICK_LAUNCH(argmax_rows_kernel, dim3((int)g), dim3(NT), 0, ST, x, (long*)ids, (long)rows, V, (long)ld);
+  return ick::launch_status("argmax_rows");
+}
+
+}  // extern "C"

@@ -23,6 +23,14 @@ inline int launch_status(const char* what) {
   return 0;
 }
 
+// hipGetLastError() is sticky per host thread: a benign failure recorded by ANOTHER library's earlier runtime call
+// (e.g. a device probe during framework start-up) must not be reported as this launch's status, so clear it first.
+#define ICK_LAUNCH(...)            \
+  do {                             \
+    (void)hipGetLastError();       \
+    hipLaunchKernelGGL(__VA_ARGS__); \
+  } while (0)
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace ick

@@ -29,7 +29,7 @@ constexpr int NT = 256;
 
 struct P {  // kernel parameters (by value)
   const float* A; const float* B; float* C;
-  const float* bias; const float* residual; float* stat_sum; float* stat_sq;
+  const float* bias; const float* residual; double* stat_sum; double* stat_sq;
   int M, N, K;
   long lda, ldb, ldc, ldr;
   int batch_inner;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
     if (p.stat_sum) {  // BatchNorm batch statistics of the raw product
       ssum += __shfl_xor(ssum, 32);
       ssq += __shfl_xor(ssq, 32);
-      if (lane < 32 && nok) { atomicAdd(p.stat_sum + n, ssum); atomicAdd(p.stat_sq + n, ssq); }
+      if (lane < 32 && nok) { atomicAdd(p.stat_sum + n, (double)ssum); atomicAdd(p.stat_sq + n, (double)ssq); }  // fp64: var = E[x^2]-E[x]^2 must not cancel
     }
   }
 }
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
 template <int OP, int BM, int BN>
 int launch(const P& p, int nz, hipStream_t st) {
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, nz);
-  hipLaunchKernelGGL((igemm_f32_kernel<OP, BM, BN>), grid, dim3(NT), 0, st, p);
+  ICK_LAUNCH((igemm_f32_kernel<OP, BM, BN>), grid, dim3(NT), 0, st, p);
   return ick::launch_status("igemm_f32");
 }
 

@@ -71,17 +71,19 @@ __global__ void vit_assemble_kernel(const float* __restrict__ patch, const float
 // ------------------------------------------------------------------ BatchNorm
 // finalize batch statistics gathered by the conv epilogue: mean/var -> (scale, shift), saved mean / invstd,
 // running-stat update with the unbiased variance (nn.BatchNorm2d train mode, momentum 0.1)
-__global__ void bn_finalize_kernel(const float* __restrict__ sum, const float* __restrict__ sq, float count,
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sq, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
                                    float* __restrict__ sinv, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const float mean = sum[c] / count;
-  float var = sq[c] / count - mean * mean;
-  var = var > 0.f ? var : 0.f;
-  const float inv = rsqrtf(var + eps);
+  const double meand = sum[c] / (double)count;
+  double vard = sq[c] / (double)count - meand * meand;      // fp64 accumulators: no cancellation
+  vard = vard > 0.0 ? vard : 0.0;
+  const float mean = (float)meand;
+  const float var = (float)vard;
+  const float inv = (float)(1.0 / sqrt(vard + (double)eps));
   const float g = gamma[c];
   scale[c] = g * inv;
   shift[c] = beta[c] - mean * g * inv;
@@ -358,7 +360,8 @@ __global__ void embedding_fwd_kernel(const long* __restrict__ ids, const float* 
     const long r = i / D4; const int d = (int)(i - r * D4);
     float4 v = reinterpret_cast<const float4*>(table)[ids[r] * D4 + d];
     if (pe) {
-      const float4 e = reinterpret_cast<const float4*>(pe)[(r / per_pos) * D4 + d];
+      const long pr = per_pos > 0 ? r / per_pos : r % (-per_pos);   // position of row r (seq-first / batch-first)
+      const float4 e = reinterpret_cast<const float4*>(pe)[pr * D4 + d];
       v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
     }
     reinterpret_cast<float4*>(out)[i] = v;
@@ -411,6 +414,24 @@ __global__ void token_pool_bwd_kernel(const float* __restrict__ dy, float* __res
   }
 }
 
+
+// counter-based dropout: keep(i) is a pure function of (seed, i), so the backward pass regenerates the mask
+// instead of storing it.  y = x * keep / (1-p).  (The reference's nn.Dropout draws from torch's Philox stream;
+// masks cannot match bit-for-bit, parity runs use p = 0 — SURVEY.md fact 7.)
+__device__ __forceinline__ unsigned mix32(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned)((z ^ (z >> 31)) >> 32);
+}
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p, float inv_keep,
+                               unsigned long long seed, const long* __restrict__ step) {
+  if (step) seed += (unsigned long long)(*step) * 0x9E3779B97F4A7C15ull;   // device-resident step counter (graph replay)
+  const unsigned thr = (unsigned)(p * 4294967296.0);
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    y[i] = mix32(seed * 0x100000001B3ull + (unsigned long long)i) >= thr ? x[i] * inv_keep : 0.f;
+}
+
 }  // namespace
 
 #define ST static_cast<hipStream_t>(stream)
@@ -420,30 +441,30 @@ extern "C" {
 int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stream) {
   ICK_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "ick_nchw3_to_nhwc4: bad arguments");
   const long npix = (long)B * H * W;
-  hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3(grid_for(npix)), dim3(NT), 0, ST, x, y, npix, (long)H * W);
+  ICK_LAUNCH(nchw3_to_nhwc4_kernel, dim3(grid_for(npix)), dim3(NT), 0, ST, x, y, npix, (long)H * W);
   return ick::launch_status("nchw3_to_nhwc4");
 }
 
 int ick_patchify16(const float* x, float* y, int B, int HW, void* stream) {
   ICK_REQUIRE(x && y && B > 0 && HW % 16 == 0, "ick_patchify16: bad arguments");
   const int G = HW / 16;
-  hipLaunchKernelGGL(patchify16_kernel, dim3(grid_for((long)B * G * G * 192)), dim3(NT), 0, ST, x, y, B, HW, G);
+  ICK_LAUNCH(patchify16_kernel, dim3(grid_for((long)B * G * G * 192)), dim3(NT), 0, ST, x, y, B, HW, G);
   return ick::launch_status("patchify16");
 }
 
 int ick_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int Ntok, int D, void* stream) {
   ICK_REQUIRE(patch && cls && pos && x && D % 4 == 0, "ick_vit_assemble: bad arguments");
-  hipLaunchKernelGGL(vit_assemble_kernel, dim3(grid_for((long)B * Ntok * (D / 4))), dim3(NT), 0, ST, patch, cls, pos, x, B,
+  ICK_LAUNCH(vit_assemble_kernel, dim3(grid_for((long)B * Ntok * (D / 4))), dim3(NT), 0, ST, patch, cls, pos, x, B,
                      Ntok, D / 4);
   return ick::launch_status("vit_assemble");
 }
 
-int ick_bn_finalize(const float* sum, const float* sq, float count, const float* gamma, const float* beta, float* rmean,
+int ick_bn_finalize(const double* sum, const double* sq, float count, const float* gamma, const float* beta, float* rmean,
                     float* rvar, float momentum, float eps, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int C, void* stream) {
   ICK_REQUIRE(sum && sq && gamma && beta && scale && shift && save_mean && save_invstd && C > 0 && count > 0,
               "ick_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum, sq, count, gamma, beta, rmean, rvar,
+  ICK_LAUNCH(bn_finalize_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum, sq, count, gamma, beta, rmean, rvar,
                      momentum, eps, scale, shift, save_mean, save_invstd, C);
   return ick::launch_status("bn_finalize");
 }
@@ -451,7 +472,7 @@ int ick_bn_finalize(const float* sum, const float* sq, float count, const float*
 int ick_bn_eval_coeffs(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
                        float* scale, float* shift, int C, void* stream) {
   ICK_REQUIRE(gamma && beta && rmean && rvar && scale && shift && C > 0, "ick_bn_eval_coeffs: bad arguments");
-  hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, gamma, beta, rmean, rvar, eps, scale,
+  ICK_LAUNCH(bn_eval_coeffs_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, gamma, beta, rmean, rvar, eps, scale,
                      shift, C);
   return ick::launch_status("bn_eval_coeffs");
 }
@@ -460,7 +481,7 @@ int ick_scale_shift_act(const float* x, const float* scale, const float* shift, 
                         int C, int relu, void* stream) {
   ICK_REQUIRE(x && scale && shift && y && C % 4 == 0 && M > 0, "ick_scale_shift_act: bad arguments (C %% 4)");
   const long total4 = M * (C / 4);
-  hipLaunchKernelGGL(scale_shift_act_kernel, dim3(grid_for(total4)), dim3(NT), 0, ST, x, scale, shift, residual, y, total4,
+  ICK_LAUNCH(scale_shift_act_kernel, dim3(grid_for(total4)), dim3(NT), 0, ST, x, scale, shift, residual, y, total4,
                      C / 4, relu);
   return ick::launch_status("scale_shift_act");
 }
@@ -476,7 +497,7 @@ int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const flo
   long gy = (M + rows * 32 - 1) / (rows * 32);   // ~32 rows per thread
   if (gy > 512) gy = 512;
   if (gy < 1) gy = 1;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, M, C);
+  ICK_LAUNCH(bn_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, M, C);
   return ick::launch_status("bn_bwd_reduce");
 }
 
@@ -485,7 +506,7 @@ int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const floa
                      int use_batch_stats, void* stream) {
   ICK_REQUIRE(dy && x && mean && invstd && gamma && dx && C % 4 == 0 && M > 0, "ick_bn_bwd_apply: bad arguments");
   const long total4 = M * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, sum_g,
+  ICK_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, sum_g,
                      sum_gx, 1.0f / (float)M, dx, g_out, total4, C / 4, use_batch_stats);
   return ick::launch_status("bn_bwd_apply");
 }
@@ -493,7 +514,7 @@ int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const floa
 int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
   ICK_REQUIRE(x && y && C % 4 == 0, "ick_maxpool3x3s2: bad arguments");
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(NT), 0, ST, x, y, B, H, W, C / 4,
+  ICK_LAUNCH(maxpool3x3s2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(NT), 0, ST, x, y, B, H, W, C / 4,
                      Ho, Wo);
   return ick::launch_status("maxpool3x3s2");
 }
@@ -501,7 +522,7 @@ int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void*
 int ick_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows,
                       int D, float eps, void* stream) {
   ICK_REQUIRE(x && gamma && beta && y && D % 4 == 0 && rows > 0, "ick_layernorm_fwd: bad arguments (D %% 4)");
-  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, x, gamma, beta, y, mean, rstd, rows, D, eps);
+  ICK_LAUNCH(layernorm_fwd_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, x, gamma, beta, y, mean, rstd, rows, D, eps);
   return ick::launch_status("layernorm_fwd");
 }
 
@@ -509,66 +530,73 @@ int ick_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
                       float* dgamma, float* dbeta, long rows, int D, void* stream) {
   ICK_REQUIRE(dy && x && gamma && mean && rstd && dx && rows > 0 && D > 0 && D <= 4096, "ick_layernorm_bwd: bad arguments");
   ICK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "ick_layernorm_bwd: dgamma and dbeta go together");
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(grid_for(rows, 16, 1024)), dim3(NT), 2 * D * sizeof(float), ST, dy, x, gamma,
+  ICK_LAUNCH(layernorm_bwd_kernel, dim3(grid_for(rows, 16, 1024)), dim3(NT), 2 * D * sizeof(float), ST, dy, x, gamma,
                      mean, rstd, dx, dgamma, dbeta, rows, D);
   return ick::launch_status("layernorm_bwd");
 }
 
 int ick_softmax_rows(float* s, long rows, int L, int ld, float scale, int causal, int Lq, void* stream) {
   ICK_REQUIRE(s && rows > 0 && L > 0 && ld >= L && (!causal || Lq > 0), "ick_softmax_rows: bad arguments");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, s, rows, L, ld, scale, causal, Lq);
+  ICK_LAUNCH(softmax_rows_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, s, rows, L, ld, scale, causal, Lq);
   return ick::launch_status("softmax_rows");
 }
 
 int ick_softmax_bwd_rows(float* dp, const float* p, long rows, int L, int ld, float scale, void* stream) {
   ICK_REQUIRE(dp && p && rows > 0 && L > 0 && ld >= L, "ick_softmax_bwd_rows: bad arguments");
-  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, dp, p, rows, L, ld, scale);
+  ICK_LAUNCH(softmax_bwd_rows_kernel, dim3(grid_for(rows, 4)), dim3(NT), 0, ST, dp, p, rows, L, ld, scale);
   return ick::launch_status("softmax_bwd_rows");
 }
 
 int ick_colsum(const float* x, float* out, long M, int N, long ld, void* stream) {
   ICK_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, "ick_colsum: bad arguments");
   long gy = (M + 63) / 64; if (gy > 256) gy = 256;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + NT - 1) / NT, (int)gy), dim3(NT), 0, ST, x, out, M, N, ld);
+  ICK_LAUNCH(colsum_kernel, dim3((N + NT - 1) / NT, (int)gy), dim3(NT), 0, ST, x, out, M, N, ld);
   return ick::launch_status("colsum");
 }
 
 int ick_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream) {
   ICK_REQUIRE(dy && y && dx && n % 4 == 0, "ick_relu_bwd: n %% 4");
-  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, ST, dy, y, dx, n / 4);
+  ICK_LAUNCH(relu_bwd_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, ST, dy, y, dx, n / 4);
   return ick::launch_status("relu_bwd");
 }
 
 int ick_add(const float* a, const float* b, float* y, long n, void* stream) {
   ICK_REQUIRE(a && b && y && n % 4 == 0, "ick_add: n %% 4");
-  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, ST, a, b, y, n / 4);
+  ICK_LAUNCH(add_kernel, dim3(grid_for(n / 4)), dim3(NT), 0, ST, a, b, y, n / 4);
   return ick::launch_status("add");
 }
 
 int ick_embedding_fwd(const int64_t* ids, const float* table, const float* pe, float* out, long n, int D, int per_pos,
                       void* stream) {
   ICK_REQUIRE(ids && table && out && D % 4 == 0 && n > 0, "ick_embedding_fwd: bad arguments");
-  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(grid_for(n * (D / 4))), dim3(NT), 0, ST, (const long*)ids, table, pe, out, n,
-                     D / 4, per_pos > 0 ? per_pos : 1);
+  ICK_LAUNCH(embedding_fwd_kernel, dim3(grid_for(n * (D / 4))), dim3(NT), 0, ST, (const long*)ids, table, pe, out, n,
+                     D / 4, per_pos != 0 ? per_pos : 1);
   return ick::launch_status("embedding_fwd");
 }
 
 int ick_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, long n, int D, void* stream) {
   ICK_REQUIRE(ids && dout && dtable && n > 0 && D > 0, "ick_embedding_bwd: bad arguments");
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(n * D)), dim3(NT), 0, ST, (const long*)ids, dout, dtable, n, D);
+  ICK_LAUNCH(embedding_bwd_kernel, dim3(grid_for(n * D)), dim3(NT), 0, ST, (const long*)ids, dout, dtable, n, D);
   return ick::launch_status("embedding_bwd");
 }
 
 int ick_token_pool_fwd(const float* x, float* y, int B, int L, int Lo, int D, void* stream) {
   ICK_REQUIRE(x && y && D % 4 == 0 && Lo > 0 && L >= Lo, "ick_token_pool_fwd: bad arguments");
-  hipLaunchKernelGGL(token_pool_fwd_kernel, dim3(grid_for((long)B * Lo * (D / 4))), dim3(NT), 0, ST, x, y, B, L, Lo, D / 4);
+  ICK_LAUNCH(token_pool_fwd_kernel, dim3(grid_for((long)B * Lo * (D / 4))), dim3(NT), 0, ST, x, y, B, L, Lo, D / 4);
   return ick::launch_status("token_pool_fwd");
 }
 
 int ick_token_pool_bwd(const float* dy, float* dx, int B, int L, int Lo, int D, void* stream) {
   ICK_REQUIRE(dy && dx && D % 4 == 0 && Lo > 0 && L >= Lo, "ick_token_pool_bwd: bad arguments");
-  hipLaunchKernelGGL(token_pool_bwd_kernel, dim3(grid_for((long)B * L * (D / 4))), dim3(NT), 0, ST, dy, dx, B, L, Lo, D / 4);
+  ICK_LAUNCH(token_pool_bwd_kernel, dim3(grid_for((long)B * L * (D / 4))), dim3(NT), 0, ST, dy, dx, B, L, Lo, D / 4);
   return ick::launch_status("token_pool_bwd");
+}
+
+int ick_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const int64_t* step, void* stream) {
+  ICK_REQUIRE(x && y && n > 0 && p >= 0.f && p < 1.f, "ick_dropout: bad arguments");
+  ICK_LAUNCH(dropout_kernel, dim3(grid_for(n)), dim3(NT), 0, ST, x, y, (long)n, p, 1.0f / (1.0f - p),
+                     (unsigned long long)seed, (const long*)step);
+  return ick::launch_status("dropout");
 }
 
 }  // extern "C"

@@ -1,0 +1,96 @@
+// optim.hip — the optimizer tail of the KD step as flat-buffer kernels
+// (reference: /root/reference/src/train_student_kd.py:292-299 — clip_grad_norm_(max_norm=1.0) then AdamW(wd=0.01)).
+// Parameters, gradients and both Adam moments live in flat fp32 buffers (one segment per LR group), so the
+// global gradient norm is one streaming reduction and the update is one fused pass per group:
+// read p,g,m,v / write p,m,v = 28 B per parameter (HBM-bound).
+#include "ick_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__global__ void sumsq_partial_kernel(const float* __restrict__ x, long n, float* __restrict__ partial) {
+  __shared__ float red[NT / 64];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0) for (long i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// norm_out[0] = sqrt(sum partial [+ norm_out[0]^2 if accumulate]) ; deterministic single-block tree
+__global__ void norm_finalize_kernel(const float* __restrict__ partial, int n, float* __restrict__ norm_out, int accumulate) {
+  __shared__ float red[NT / 64];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += NT) s += partial[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = (red[0] + red[1]) + (red[2] + red[3]);
+    if (accumulate) t += norm_out[0] * norm_out[0];
+    norm_out[0] = sqrtf(t);
+  }
+}
+
+// torch.optim.AdamW single step with the clip coefficient folded in:
+// (hyper != NULL: lr, 1-beta1^t, 1-beta2^t are read from device memory so a captured graph follows the schedule)
+//   g' = g * min(1, max_norm / (norm + 1e-6)) * inv_scale ; p *= 1 - lr*wd ; m,v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                             long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                             const float* __restrict__ norm, float max_norm, float inv_scale, int write_clipped,
+                             const float* __restrict__ hyper) {
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }  // device-resident schedule (hipGraph replay)
+  float coef = inv_scale;
+  if (norm) { const float c = max_norm / (norm[0] * inv_scale + 1e-6f); coef *= (c < 1.f ? c : 1.f); }
+  const float step = lr / bc1, isb2 = rsqrtf(bc2), decay = 1.f - lr * wd;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float gg = g[i] * coef;
+    const float mm = b1 * m[i] + (1.f - b1) * gg;
+    const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+    m[i] = mm; v[i] = vv;
+    p[i] = p[i] * decay - step * mm / (sqrtf(vv) * isb2 + eps);
+    if (write_clipped) g[i] = gg;
+  }
+}
+
+}  // namespace
+
+#define ST static_cast<hipStream_t>(stream)
+
+extern "C" {
+
+// norm_out[0] = ||x||_2 (accumulate != 0: combines with the norm already stored there: sqrt(old^2 + ||x||^2)).
+// workspace: >= 1024 floats.
+int ick_grad_norm(const float* x, int64_t n, float* workspace, float* norm_out, int accumulate, void* stream) {
+  ICK_REQUIRE(x && workspace && norm_out && n > 0 && ick::aligned16(x), "ick_grad_norm: bad arguments");
+  long g = (n / 4 + NT - 1) / NT; if (g > 1024) g = 1024; if (g < 1) g = 1;
+  ICK_LAUNCH(sumsq_partial_kernel, dim3((int)g), dim3(NT), 0, ST, x, (long)n, workspace);
+  ICK_LAUNCH(norm_finalize_kernel, dim3(1), dim3(NT), 0, ST, workspace, (int)g, norm_out, accumulate);
+  return ick::launch_status("grad_norm");
+}
+
+int ick_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, const float* norm, float max_norm, float inv_scale, int write_clipped,
+                   const float* hyper, void* stream) {
+  ICK_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || hyper), "ick_adamw_step: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  long gr = (n + NT - 1) / NT; if (gr > 4096) gr = 4096;
+  ICK_LAUNCH(adamw_kernel, dim3((int)gr), dim3(NT), 0, ST, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay,
+                     bc1, bc2, norm, max_norm, inv_scale, write_clipped, hyper);
+  return ick::launch_status("adamw_step");
+}
+
+}  // extern "C"

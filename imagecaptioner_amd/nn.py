@@ -1,0 +1,375 @@
+"""HIP-backed building blocks: torch.autograd.Functions with hand-written backward passes that
+call libick.so through imagecaptioner_amd.ops, and thin nn.Module parameter holders with the
+reference's state_dict names.  No function here computes with torch operators: torch provides
+device memory (empty/zeros), the autograd graph between the large fused Functions, and streams.
+
+Gradient convention: a Function accumulates parameter gradients IN PLACE into `param.grad`
+(allocating zeros on first use) and returns None for those inputs — the same end state autograd
+produces, without one extra read-modify-write pass per parameter, and it lets the trainer alias
+every `.grad` into one flat fp32 buffer for a single RCCL all-reduce and a fused AdamW.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import ops
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU
+
+_seed_state = {"seed": 0x1234ABCD, "ctr": 0}
+
+
+def manual_seed(seed: int) -> None:
+    """Seed of the counter-based dropout generator (csrc/norm_act.hip dropout_kernel)."""
+    _seed_state["seed"] = int(seed) & 0xFFFFFFFF
+    _seed_state["ctr"] = 0
+
+
+def _next_seed() -> int:
+    _seed_state["ctr"] += 1
+    return ((_seed_state["seed"] << 20) ^ _seed_state["ctr"]) & 0xFFFFFFFFFFFF
+
+
+def grad_buf(p: torch.Tensor) -> torch.Tensor:
+    if p.grad is None:
+        p.grad = torch.zeros_like(p)      # preserve_format keeps channels_last conv weights channels_last
+    return p.grad
+
+
+def _c(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ----------------------------------------------------------------------------- Functions
+class LinearFn(Function):
+    """y = act(x W^T + b) [+ residual]; act in {none, relu}; residual only with act none."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, act, residual):
+        x = _c(x)
+        if residual is not None:
+            assert act == ACT_NONE
+            residual = _c(residual)
+        y = ops.linear_fwd(x, w, b, act, residual)
+        ctx.x, ctx.w, ctx.b, ctx.act = x, w, b, act
+        ctx.y = y if act == ACT_RELU else None
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        g = ops.relu_bwd(dy, ctx.y) if ctx.act == ACT_RELU else dy
+        dx = ops.linear_bwd_data(g, ctx.w) if ctx.needs_input_grad[0] else None
+        if ctx.w.requires_grad:
+            ops.linear_bwd_weight(g, ctx.x, grad_buf(ctx.w))
+        if ctx.b is not None and ctx.b.requires_grad:
+            ops.colsum_into(g, grad_buf(ctx.b))
+        return dx, None, None, None, (dy if ctx.has_res and ctx.needs_input_grad[4] else None)
+
+
+def linear(x, w, b=None, act=ACT_NONE, residual=None):
+    return LinearFn.apply(x, w, b, act, residual)
+
+
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, g, b, eps):
+        x = _c(x)
+        y, mean, rstd = ops.layernorm_fwd(x, g, b, eps, save=True)
+        ctx.x, ctx.g, ctx.b, ctx.mean, ctx.rstd = x, g, b, mean, rstd
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        need = ctx.g.requires_grad
+        dx = ops.layernorm_bwd(_c(dy), ctx.x, ctx.g, ctx.mean, ctx.rstd, grad_buf(ctx.g) if need else None,
+                               grad_buf(ctx.b) if need else None)
+        return dx, None, None, None
+
+
+def layer_norm(x, g, b, eps=1e-5):
+    return LayerNormFn.apply(x, g, b, eps)
+
+
+class DropoutFn(Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = _c(x)
+        y = torch.empty_like(x)
+        ops.dropout(x, y, p, seed)
+        ctx.p, ctx.seed = p, seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty_like(dy)
+        ops.dropout(dy, dx, ctx.p, ctx.seed)
+        return dx, None, None
+
+
+def dropout(x, p: float, training: bool):
+    if not training or p <= 0.0:
+        return x
+    return DropoutFn.apply(x, p, _next_seed())
+
+
+class EmbeddingFn(Function):
+    @staticmethod
+    def forward(ctx, ids, table):
+        ids = _c(ids)
+        ctx.ids, ctx.table = ids, table
+        return ops.embedding_fwd(ids, table)
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.table.requires_grad:
+            ops.embedding_bwd(ctx.ids, _c(dout), grad_buf(ctx.table))
+        return None, None
+
+
+class SelfAttentionCoreFn(Function):
+    """softmax(QK^T/sqrt(d))V over a packed in_proj output qkv [(B*L)][3E] (nn.MultiheadAttention core)."""
+
+    @staticmethod
+    def forward(ctx, qkv, B, H, L, d, p_drop, seed):
+        qkv = _c(qkv)
+        E = H * d
+        O, P = ops.attention_fwd(qkv, 0, 3 * E, qkv, E, 3 * E, qkv, 2 * E, 3 * E, B, H, L, L, d, False, p_drop, seed)
+        ctx.qkv, ctx.P, ctx.dims, ctx.drop = qkv, P, (B, H, L, d), (p_drop, seed)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        B, H, L, d = ctx.dims
+        E = H * d
+        dqkv = ops.empty(B * L, 3 * E, device=dO.device)
+        ops.attention_bwd(_c(dO), ctx.P, ctx.qkv, 0, 3 * E, ctx.qkv, E, 3 * E, ctx.qkv, 2 * E, 3 * E,
+                          dqkv, 0, 3 * E, dqkv, E, 3 * E, dqkv, 2 * E, 3 * E, B, H, L, L, d, *ctx.drop)
+        return dqkv, None, None, None, None, None, None
+
+
+class TokenPoolFn(Function):
+    @staticmethod
+    def forward(ctx, x, Lo):
+        x = _c(x)
+        ctx.L = x.shape[1]
+        return ops.token_pool_fwd(x, Lo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.token_pool_bwd(_c(dy), ctx.L), None
+
+
+# ----------------------------------------------------------------------------- parameter holders with HIP forward
+class Linear(nn.Linear):
+    """nn.Linear's parameters and init (state_dict: weight, bias); forward on the MFMA GEMM."""
+
+    def forward(self, x):
+        return linear(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    def forward(self, x):
+        return layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class Embedding(nn.Embedding):
+    def forward(self, ids):
+        return EmbeddingFn.apply(ids, self.weight)
+
+
+class Dropout(nn.Dropout):
+    def forward(self, x):
+        return dropout(x, self.p, self.training)
+
+
+class ReLU(nn.Module):
+    """Placeholder keeping nn.Sequential indices of the reference (the ReLU itself is fused into the GEMM epilogue)."""
+
+    def forward(self, x):
+        raise RuntimeError("fused into the preceding Linear; call the owning block")
+
+
+class Identity(nn.Identity):
+    pass
+
+
+class Conv2d(nn.Module):
+    """Weight holder: logical (Cout,Cin,R,S) like nn.Conv2d (state_dict compatible), physically channels_last,
+    i.e. [Cout][R][S][Cin] — the layout the implicit-GEMM kernels read."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0):
+        super().__init__()
+        w = torch.empty(cout, cin, k, k)
+        nn.init.kaiming_normal_(w, mode="fan_out", nonlinearity="relu")
+        self.weight = nn.Parameter(w.contiguous(memory_format=torch.channels_last))
+        self.stride, self.padding, self.k = stride, padding, k
+
+    def packed(self) -> torch.Tensor:
+        w = self.weight
+        if not w.is_contiguous(memory_format=torch.channels_last):
+            # a loader replaced .data with an NCHW tensor: restore the physical layout once
+            w.data = w.data.contiguous(memory_format=torch.channels_last)
+        return w.permute(0, 2, 3, 1)
+
+    def packed_grad(self) -> torch.Tensor:
+        return grad_buf(self.weight).permute(0, 2, 3, 1)
+
+
+class BatchNorm2d(nn.Module):
+    def __init__(self, c, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.eps, self.momentum = eps, momentum
+
+
+def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool, w_packed=None):
+    """raw = conv(x); y = [relu](bn(raw) [+ residual]).  Train mode: batch statistics from the conv epilogue,
+    running stats updated (also for frozen layers).  Returns (y, raw, mean, invstd)."""
+    w = w_packed if w_packed is not None else conv.packed()
+    if train:
+        C = w.shape[0]
+        stats = torch.zeros(2, C, dtype=torch.float64, device=x.device)     # fp64 sum / sum-of-squares accumulators
+        raw = ops.conv_fwd(x, w, conv.stride, conv.padding, stats=(stats[0], stats[1]))
+        count = raw.numel() // C
+        co = ops.bn_finalize(stats[0], stats[1], count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                             bn.momentum, bn.eps)
+        bn.num_batches_tracked += 1          # bookkeeping counter (int64), not part of the arithmetic
+        y = ops.scale_shift_act(raw, co[0], co[1], residual, relu)
+        return y, raw, co[2], co[3]
+    co = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    raw = ops.conv_fwd(x, w, conv.stride, conv.padding)
+    y = ops.scale_shift_act(raw, co[0], co[1], residual, relu)
+    return y, None, None, None
+
+
+class Bottleneck(nn.Module):
+    """torchvision Bottleneck (v1.5: stride on the 3x3) — holder with torchvision's attribute names."""
+
+    def __init__(self, inplanes, planes, stride=1, downsample=False):
+        super().__init__()
+        self.conv1 = Conv2d(inplanes, planes, 1)
+        self.bn1 = BatchNorm2d(planes)
+        self.conv2 = Conv2d(planes, planes, 3, stride=stride, padding=1)
+        self.bn2 = BatchNorm2d(planes)
+        self.conv3 = Conv2d(planes, planes * 4, 1)
+        self.bn3 = BatchNorm2d(planes * 4)
+        self.downsample = nn.Sequential(Conv2d(inplanes, planes * 4, 1, stride=stride), BatchNorm2d(planes * 4)) \
+            if downsample else None
+
+
+class _Placeholder(nn.Module):
+    """Parameter-free child that only keeps the Sequential indices of torchvision's resnet children (relu, maxpool)."""
+
+
+def build_resnet50_children() -> nn.Sequential:
+    """list(resnet50.children())[:-2] as an nn.Sequential: 0 conv1, 1 bn1, 2 relu, 3 maxpool, 4-7 layer1-4
+    (reference: /root/reference/src/student_model.py:16-20)."""
+    mods: List[nn.Module] = [Conv2d(3, 64, 7, stride=2, padding=3), BatchNorm2d(64), _Placeholder(), _Placeholder()]
+    inpl = 64
+    for planes, blocks, stride in ((64, 3, 1), (128, 4, 2), (256, 6, 2), (512, 3, 2)):
+        layer = [Bottleneck(inpl, planes, stride, downsample=True)]
+        inpl = planes * 4
+        for _ in range(1, blocks):
+            layer.append(Bottleneck(inpl, planes))
+        mods.append(nn.Sequential(*layer))
+    return nn.Sequential(*mods)
+
+
+def _block_trainable(blk: Bottleneck) -> bool:
+    return any(p.requires_grad for p in blk.parameters())
+
+
+class ResNetTrunkFn(Function):
+    """The whole ResNet-50 trunk as ONE autograd node with a hand-scheduled backward: conv raw outputs and block
+    outputs are kept only for blocks at/after the first trainable one; residual adds, ReLU masks and BatchNorm
+    reductions are fused into the kernels on both passes; weight gradients accumulate straight into .grad."""
+
+    @staticmethod
+    def forward(ctx, images, resnet: nn.Sequential, train: bool, *params):
+        images = _c(images)
+        x4 = ops.nchw3_to_nhwc4(images)
+        stem: Conv2d = resnet[0]
+        if any(p.requires_grad for p in list(stem.parameters()) + list(resnet[1].parameters())):
+            raise NotImplementedError("the 7x7 stem is frozen in the reference (student_model.py:23-27); its backward is not built")
+        w4 = ops.nchw3_to_nhwc4(_c(stem.weight.detach()))          # (64,3,7,7) -> (64,7,7,4), zero 4th channel
+        y, _, _, _ = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4)
+        y = ops.maxpool3x3s2(y)
+        blocks: List[Bottleneck] = [b for li in (4, 5, 6, 7) for b in resnet[li]]
+        first = next((i for i, b in enumerate(blocks) if _block_trainable(b)), len(blocks))
+        want_bwd = any(ctx.needs_input_grad) and first < len(blocks)   # (forward itself always runs in no-grad mode)
+        recs = []
+        for i, blk in enumerate(blocks):
+            keep = want_bwd and i >= first
+            a1, r1, m1, i1 = conv_bn(y, blk.conv1, blk.bn1, True, None, train)
+            a2, r2, m2, i2 = conv_bn(a1, blk.conv2, blk.bn2, True, None, train)
+            if blk.downsample is not None:
+                idt, rd, md, idv = conv_bn(y, blk.downsample[0], blk.downsample[1], False, None, train)
+            else:
+                idt, rd, md, idv = y, None, None, None
+            out, r3, m3, i3 = conv_bn(a2, blk.conv3, blk.bn3, True, idt, train)
+            if keep:
+                recs.append(dict(x=y, a1=a1, r1=r1, m1=m1, i1=i1, a2=a2, r2=r2, m2=m2, i2=i2, out=out, r3=r3, m3=m3,
+                                 i3=i3, rd=rd, md=md, idv=idv))
+            y = out
+        ctx.blocks, ctx.first, ctx.recs, ctx.train = blocks, first, recs, train
+        Nb, H, W, C = y.shape
+        return y.view(Nb, H * W, C)                                  # (B,49,2048): NHWC is already "permute(0,2,1)"
+
+    @staticmethod
+    def backward(ctx, dy):
+        blocks, first, recs, train = ctx.blocks, ctx.first, ctx.recs, ctx.train
+        if not recs:
+            return (None,) * (3 + sum(1 for b in blocks for _ in b.parameters()) + 3)
+        d = _c(dy).view(recs[-1]["out"].shape)
+        for i in range(len(blocks) - 1, first - 1, -1):
+            blk, r = blocks[i], recs[i - first]
+            need_in = i > first
+
+            def bnb(dyv, ymask, raw, mean, inv, bn, want_g=False):
+                if train:
+                    return ops.bn_bwd(dyv, ymask, raw, mean, inv, bn.weight, grad_buf(bn.weight) if bn.weight.requires_grad else None,
+                                      grad_buf(bn.bias) if bn.weight.requires_grad else None, want_g, True)
+                raise NotImplementedError("backward through eval-mode BatchNorm is not needed by the KD step")
+
+            def wgrad(conv, dyv, xin):
+                if conv.weight.requires_grad:
+                    ops.conv_wgrad(dyv, xin, conv.packed_grad(), conv.stride, conv.padding)
+
+            dx3, g3 = bnb(d, r["out"], r["r3"], r["m3"], r["i3"], blk.bn3, want_g=True)
+            wgrad(blk.conv3, dx3, r["a2"])
+            da2 = ops.conv_dgrad(dx3, blk.conv3.packed(), r["a2"].shape[1:3], 1, 0)
+            dx2, _ = bnb(da2, r["a2"], r["r2"], r["m2"], r["i2"], blk.bn2)
+            wgrad(blk.conv2, dx2, r["a1"])
+            da1 = ops.conv_dgrad(dx2, blk.conv2.packed(), r["a1"].shape[1:3], blk.conv2.stride, 1)
+            dx1, _ = bnb(da1, r["a1"], r["r1"], r["m1"], r["i1"], blk.bn1)
+            wgrad(blk.conv1, dx1, r["x"])
+            hw = r["x"].shape[1:3]
+            if blk.downsample is None:
+                d = ops.conv_dgrad(dx1, blk.conv1.packed(), hw, 1, 0, residual=g3) if need_in else None
+            else:
+                dsc, dsb = blk.downsample[0], blk.downsample[1]
+                dxd, _ = bnb(g3, None, r["rd"], r["md"], r["idv"], dsb)
+                wgrad(dsc, dxd, r["x"])
+                if need_in:
+                    d = ops.conv_dgrad(dx1, blk.conv1.packed(), hw, 1, 0)
+                    ops.conv_dgrad(dxd, dsc.packed(), hw, dsc.stride, 0, out=d, accumulate=True)
+                else:
+                    d = None
+            recs[i - first] = None                                   # free this block's activations
+        return (None,) * (3 + len(ctx.needs_input_grad) - 3)
+
+
+def resnet_trunk(images, resnet: nn.Sequential, train: bool):
+    params = [p for p in resnet.parameters() if p.requires_grad]
+    return ResNetTrunkFn.apply(images, resnet, train, *params)

@@ -102,6 +102,17 @@ def linear_bwd_weight(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, split
         gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), N, K, M, N, K, K, accumulate=True)
 
 
+_dropout_step = {"ptr": None}     # optional device int64 counter mixed into every dropout seed (set by the trainer)
+
+
+def set_dropout_step_counter(t: Optional[torch.Tensor]) -> None:
+    _dropout_step["ptr"] = t
+
+
+def dropout(x: torch.Tensor, y: torch.Tensor, p: float, seed: int) -> None:
+    check(_lib.lib().ick_dropout(x.data_ptr(), y.data_ptr(), x.numel(), p, seed, _ptr(_dropout_step["ptr"]), _st()), "ick_dropout")
+
+
 def colsum_into(x: torch.Tensor, out: torch.Tensor) -> None:
     """out[n] += sum over rows of x (…, N)."""
     N = x.shape[-1]
@@ -142,8 +153,9 @@ def layernorm_bwd(dy, x, g, mean, rstd, dg: Optional[torch.Tensor], db: Optional
 
 # ----------------------------------------------------------------------------- attention core (unfused: GEMM + softmax + GEMM)
 def attention_fwd(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, koff: int, kld: int, v: torch.Tensor, voff: int,
-                  vld: int, B: int, H: int, Lq: int, Lk: int, d: int, causal: bool = False):
-    """softmax(Q K^T / sqrt(d)) V per (batch, head).  q/k/v are 2-D row matrices [(B*L)][ld] in which head h of
+                  vld: int, B: int, H: int, Lq: int, Lk: int, d: int, causal: bool = False, p_drop: float = 0.0,
+                  seed: int = 0):
+    """softmax(Q K^T / sqrt(d)) V per (batch, head) [dropout on the probabilities when p_drop > 0].  q/k/v are 2-D row matrices [(B*L)][ld] in which head h of
     the operand starts at column off + h*d (packed in_proj outputs).  Returns (O [B*Lq][H*d], P [B,H,Lq,Lkp]) with
     the probability rows padded to Lkp = roundup4(Lk) (pad columns are zero)."""
     E = H * d
@@ -155,25 +167,35 @@ def attention_fwd(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, koff: i
              batch=(B, H), strides=(Lq * qld, d, Lk * kld, d, H * Lq * Lkp, Lq * Lkp))
     check(_lib.lib().ick_softmax_rows(P.data_ptr(), B * H * Lq, Lk, Lkp, 1.0 / math.sqrt(d), int(causal), Lq, _st()),
           "ick_softmax_rows")
-    gemm_raw(OP_NN, P.data_ptr(), v.data_ptr() + voff * fs, O.data_ptr(), Lq, d, Lk, Lkp, vld, E,
+    Pd = P
+    if p_drop > 0.0:
+        Pd = torch.empty_like(P)
+        dropout(P, Pd, p_drop, seed)
+    gemm_raw(OP_NN, Pd.data_ptr(), v.data_ptr() + voff * fs, O.data_ptr(), Lq, d, Lk, Lkp, vld, E,
              batch=(B, H), strides=(H * Lq * Lkp, Lq * Lkp, Lk * vld, d, Lq * E, d))
     return O, P
 
 
 def attention_bwd(dO: torch.Tensor, P: torch.Tensor, q, qoff, qld, k, koff, kld, v, voff, vld,
-                  dq, dqoff, dqld, dk, dkoff, dkld, dv, dvoff, dvld, B, H, Lq, Lk, d):
+                  dq, dqoff, dqld, dk, dkoff, dkld, dv, dvoff, dvld, B, H, Lq, Lk, d, p_drop: float = 0.0, seed: int = 0):
     """Backward of attention_fwd; writes dQ/dK/dV into the given row matrices at the same packed offsets."""
     E = H * d
     fs = 4
     Lkp = P.shape[-1]
     dP = torch.empty_like(P)
     sP = (H * Lq * Lkp, Lq * Lkp)
+    Pd = P
+    if p_drop > 0.0:                      # regenerate the dropped probabilities (counter-based mask)
+        Pd = torch.empty_like(P)
+        dropout(P, Pd, p_drop, seed)
     # dP = dO V^T
     gemm_raw(OP_NT, dO.data_ptr(), v.data_ptr() + voff * fs, dP.data_ptr(), Lq, Lk, d, E, vld, Lkp,
              batch=(B, H), strides=(Lq * E, d, Lk * vld, d) + sP)
     # dV = P^T dO
-    gemm_raw(OP_TN, P.data_ptr(), dO.data_ptr(), dv.data_ptr() + dvoff * fs, Lk, d, Lq, Lkp, E, dvld,
+    gemm_raw(OP_TN, Pd.data_ptr(), dO.data_ptr(), dv.data_ptr() + dvoff * fs, Lk, d, Lq, Lkp, E, dvld,
              batch=(B, H), strides=sP + (Lq * E, d, Lk * dvld, d))
+    if p_drop > 0.0:
+        dropout(dP, dP, p_drop, seed)     # dP <- mask * dP / (1-p)
     # dS = scale * P * (dP - rowsum(dP*P))
     check(_lib.lib().ick_softmax_bwd_rows(dP.data_ptr(), P.data_ptr(), B * H * Lq, Lk, Lkp, 1.0 / math.sqrt(d), _st()),
           "ick_softmax_bwd_rows")
@@ -347,3 +369,80 @@ def token_pool_bwd(dy, L):
     dx = empty(B, L, D, device=dy.device)
     check(_lib.lib().ick_token_pool_bwd(dy.data_ptr(), dx.data_ptr(), B, L, Lo, D, _st()), "ick_token_pool_bwd")
     return dx
+
+
+# ----------------------------------------------------------------------------- decoder step kernels
+def attn_step_fwd(Uf, hW, feats, w_out, ctx_out):
+    B, L, E = feats.shape
+    check(_lib.lib().ick_attn_step_fwd(Uf.data_ptr(), hW.data_ptr(), feats.data_ptr(), w_out.data_ptr(), ctx_out.data_ptr(),
+                                       B, L, E, _st()), "ick_attn_step_fwd")
+
+
+def attn_step_bwd(dctx, w, Uf, hW, feats, dUf, dfeats, dhW):
+    B, L, E = feats.shape
+    check(_lib.lib().ick_attn_step_bwd(dctx.data_ptr(), w.data_ptr(), Uf.data_ptr(), hW.data_ptr(), feats.data_ptr(),
+                                       dUf.data_ptr(), dfeats.data_ptr(), dhW.data_ptr(), B, L, E, _st()), "ick_attn_step_bwd")
+
+
+def lstm_cell_fwd(G, b_ih, b_hh, c_prev, gates, c_out, h_out):
+    B, H = c_out.shape
+    check(_lib.lib().ick_lstm_cell_fwd(G.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), _ptr(c_prev), _ptr(gates),
+                                       c_out.data_ptr(), h_out.data_ptr(), B, H, _st()), "ick_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(dh_a, dh_b, dc_in, gates, c, c_prev, dG, dc_prev):
+    B, H = c.shape
+    check(_lib.lib().ick_lstm_cell_bwd(dh_a.data_ptr(), _ptr(dh_b), _ptr(dc_in), gates.data_ptr(), c.data_ptr(),
+                                       _ptr(c_prev), dG.data_ptr(), dc_prev.data_ptr(), B, H, _st()), "ick_lstm_cell_bwd")
+
+
+def argmax_rows(x: torch.Tensor) -> torch.Tensor:
+    V = x.shape[-1]
+    rows = x.numel() // V
+    ids = torch.empty(x.shape[:-1], dtype=torch.int64, device=x.device)
+    check(_lib.lib().ick_argmax_rows(x.data_ptr(), ids.data_ptr(), rows, V, V, _st()), "ick_argmax_rows")
+    return ids
+
+
+def gemm_nt(x: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Tensor, *, bias=None, residual=None,
+            accumulate=False, act=ACT_NONE, splitk: int = 1):
+    """out (M,N) = act(x (M,K) @ W^T + bias) [+ residual]; W given by raw pointer + row pitch (column slices of a
+    wider weight, e.g. the W_h / W_f halves of the decoder's attention matrix)."""
+    M = x.numel() // K
+    gemm_raw(OP_NT, x.data_ptr(), w_ptr, out.data_ptr(), M, N, K, K, ldb, N, bias=_ptr(bias), residual=_ptr(residual),
+             ldr=N, act=act, accumulate=accumulate, splitk=splitk)
+    return out
+
+
+def gemm_nn(dy: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Tensor, *, residual=None,
+            accumulate=False):
+    """out (M,K) = dy (M,N) @ W (N,K) [+ residual]; W by raw pointer with row pitch ldb."""
+    M = dy.numel() // N
+    gemm_raw(OP_NN, dy.data_ptr(), w_ptr, out.data_ptr(), M, K, N, N, ldb, K, residual=_ptr(residual), ldr=K,
+             accumulate=accumulate)
+    return out
+
+
+def gemm_tn_acc(dy: torch.Tensor, x: torch.Tensor, dw_ptr: int, N: int, K: int, ldc: int, splitk: int = 0):
+    """dW[N][K] (row pitch ldc, raw pointer) += dy (M,N)^T @ x (M,K)."""
+    M = dy.numel() // N
+    if splitk <= 0:
+        tiles = ((N + 127) // 128) * ((K + 127) // 128)
+        splitk = max(1, min(32, 512 // max(tiles, 1), M // 256))
+    if splitk > 1:
+        gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw_ptr, N, K, M, N, K, ldc, splitk=splitk)
+    else:
+        gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw_ptr, N, K, M, N, K, ldc, accumulate=True)
+
+
+# ----------------------------------------------------------------------------- optimizer tail
+def grad_norm(flat: torch.Tensor, workspace: torch.Tensor, norm_out: torch.Tensor, accumulate: bool = False):
+    check(_lib.lib().ick_grad_norm(flat.data_ptr(), flat.numel(), workspace.data_ptr(), norm_out.data_ptr(), int(accumulate),
+                                   _st()), "ick_grad_norm")
+
+
+def adamw_step(p, g, m, v, lr, betas, eps, wd, step, norm=None, max_norm=1.0, inv_scale=1.0, write_clipped=False,
+               hyper=None):
+    check(_lib.lib().ick_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1],
+                                    eps, wd, step, _ptr(norm), max_norm, inv_scale, int(write_clipped), _ptr(hyper), _st()),
+          "ick_adamw_step")

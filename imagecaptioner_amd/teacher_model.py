@@ -1,0 +1,193 @@
+"""MI355X-native ViT-S/16 + Transformer-decoder teacher — drop-in for the reference's
+src/teacher_model.py (/root/reference/src/teacher_model.py): same constructor, forward signature
+`(images, captions) -> (T,B,V)`, attributes callers reach into (.encoder.forward_features,
+.encoder.num_features, .encoder_projection, .embedding, .pos_encoder, .decoder, .pre_output_norm,
+.fc_out) and state_dict keys (timm ViT names under `encoder.`, nn.TransformerDecoder names).
+
+In the KD step the teacher is frozen, in eval mode, fp32 and under no_grad
+(/root/reference/src/distillation_utils.py:259-292), so this module is a forward-only HIP path:
+patch-embed / qkv / proj / MLP as fp32-MFMA GEMMs with fused bias, GELU, ReLU and residual epilogues,
+attention as batched GEMMs + row softmax, LayerNorm as a wave-per-row kernel.  torch modules are used only
+as parameter holders (names + init identical to the reference's).  Teacher training is out of scope
+(SURVEY.md §2 row 9).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import nn as hnn
+from . import ops
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU
+
+
+class PositionalEncoding(nn.Module):
+    """Sinusoid table buffer `pe` (5000,1,d) — reference :8-27.  The table is added inside the embedding gather."""
+
+    def __init__(self, d_model, dropout=0.1, max_len=5000):
+        super().__init__()
+        self.dropout = nn.Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0).transpose(0, 1).contiguous())
+
+    def table(self) -> torch.Tensor:
+        return self.pe.view(self.pe.shape[0], self.pe.shape[2])
+
+
+class _VitAttn(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _VitMlp(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _VitBlock(nn.Module):
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _VitAttn(dim, heads)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _VitMlp(dim, dim * 4)
+
+
+class _PatchEmbed(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, 16, stride=16)
+
+
+def self_attention(x2, B, L, H, w_qkv, b_qkv, causal=False):
+    """packed projection + attention core; x2 [(B*L)][E] -> O [(B*L)][E]"""
+    E = x2.shape[1]
+    qkv = ops.linear_fwd(x2, w_qkv, b_qkv)
+    O, _ = ops.attention_fwd(qkv, 0, 3 * E, qkv, E, 3 * E, qkv, 2 * E, 3 * E, B, H, L, L, E // H, causal)
+    return O
+
+
+class VisionTransformerS16(nn.Module):
+    """timm `vit_small_patch16_224` (num_classes=0) restated for the HIP path: 12 pre-norm blocks, width 384,
+    6 heads, MLP 1536, LayerNorm eps 1e-6, exact GELU, class token + learned position embedding, final norm.
+    (timm is not installed and un-pinned by the reference; names follow timm's public module layout.)"""
+
+    def __init__(self, dim=384, depth=12, heads=6):
+        super().__init__()
+        self.num_features = self.embed_dim = dim
+        self.num_heads = heads
+        self.patch_embed = _PatchEmbed(dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.randn(1, 197, dim) * 0.02)
+        self.blocks = nn.Sequential(*[_VitBlock(dim, heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+
+    @torch.no_grad()
+    def forward_features(self, images):
+        images = hnn._c(images.float())
+        B = images.shape[0]
+        D, H = self.num_features, self.num_heads
+        if images.shape[1:] != (3, 224, 224):
+            raise NotImplementedError("ViT-S/16 HIP path is built for (3,224,224) inputs")
+        patches = ops.patchify16(images)                                                  # [B*196][768]
+        pe = ops.linear_fwd(patches, self.patch_embed.proj.weight.view(D, 768), self.patch_embed.proj.bias)
+        x = ops.vit_assemble(pe, self.cls_token, self.pos_embed, B, 197, D)              # (B,197,D)
+        x2 = x.view(B * 197, D)
+        for blk in self.blocks:
+            y, _, _ = ops.layernorm_fwd(x2, blk.norm1.weight, blk.norm1.bias, 1e-6, save=False)
+            o = self_attention(y, B, 197, H, blk.attn.qkv.weight, blk.attn.qkv.bias)
+            x2 = ops.linear_fwd(o, blk.attn.proj.weight, blk.attn.proj.bias, residual=x2)
+            y, _, _ = ops.layernorm_fwd(x2, blk.norm2.weight, blk.norm2.bias, 1e-6, save=False)
+            h = ops.linear_fwd(y, blk.mlp.fc1.weight, blk.mlp.fc1.bias, act=ACT_GELU)
+            x2 = ops.linear_fwd(h, blk.mlp.fc2.weight, blk.mlp.fc2.bias, residual=x2)
+        out, _, _ = ops.layernorm_fwd(x2, self.norm.weight, self.norm.bias, 1e-6, save=False)
+        return out.view(B, 197, D)
+
+    def forward(self, images):
+        return self.forward_features(images)[:, 0]
+
+
+class CaptioningTeacher(nn.Module):
+    """reference: CaptioningTeacher, /root/reference/src/teacher_model.py:30-106."""
+
+    def __init__(self, vocab_size, embed_size=384, num_heads=12, num_decoder_layers=6, dropout=0.1):
+        super().__init__()
+        self.encoder = VisionTransformerS16()
+        encoder_dim = self.encoder.num_features
+        for name, p in self.encoder.named_parameters():      # same fine-tune flags as the reference (:43-47)
+            p.requires_grad = any(k in name for k in ("blocks.8", "blocks.9", "blocks.10", "blocks.11", "norm"))
+        self.encoder_projection = hnn.Linear(encoder_dim, embed_size) if encoder_dim != embed_size else nn.Identity()
+        self.embedding = hnn.Embedding(vocab_size, embed_size)
+        nn.init.uniform_(self.embedding.weight, -0.1, 0.1)
+        self.pos_encoder = PositionalEncoding(d_model=embed_size, dropout=dropout)
+        layer = nn.TransformerDecoderLayer(d_model=embed_size, nhead=num_heads, dim_feedforward=embed_size * 2,
+                                           dropout=dropout, batch_first=False)
+        self.decoder = nn.TransformerDecoder(layer, num_layers=num_decoder_layers)   # parameter holder (names + init)
+        self.pre_output_norm = hnn.LayerNorm(embed_size)
+        self.fc_out = hnn.Linear(embed_size, vocab_size)
+        nn.init.xavier_uniform_(self.fc_out.weight)
+        nn.init.constant_(self.fc_out.bias, 0)
+        self.dropout = nn.Dropout(p=dropout)
+        self.num_heads = num_heads
+        self.vocab_size = vocab_size
+
+    @torch.no_grad()
+    def project_memory(self, vit_tokens):
+        """encoder_projection over the 197 ViT tokens -> (B,197,E) (reference :83)."""
+        if isinstance(self.encoder_projection, nn.Identity):
+            return vit_tokens
+        return ops.linear_fwd(hnn._c(vit_tokens), self.encoder_projection.weight, self.encoder_projection.bias)
+
+    @torch.no_grad()
+    def decode(self, memory, captions):
+        """Transformer decoder over teacher-forced captions (T,B) with memory (B,197,E) -> logits (T,B,V)
+        (reference :86-104, eval mode: dropout off).  Internally batch-first; the final GEMM writes (T,B,V)."""
+        if self.training:
+            raise NotImplementedError("the HIP teacher is forward-only/eval (frozen in KD, distillation_utils.py:259-266)")
+        T, B = captions.shape
+        E, H, V = memory.shape[-1], self.num_heads, self.vocab_size
+        L = memory.shape[1]
+        mem2 = hnn._c(memory).view(B * L, E)
+        ids_bt = captions.t().contiguous()                                              # (B,T) token ids
+        x2 = ops.embedding_fwd(ids_bt, self.embedding.weight, pe=self.pos_encoder.table(), per_pos=-T).view(B * T, E)
+        for lyr in self.decoder.layers:
+            sa, ca = lyr.self_attn, lyr.multihead_attn
+            o = self_attention(x2, B, T, H, sa.in_proj_weight, sa.in_proj_bias, causal=True)
+            x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, sa.out_proj.weight, sa.out_proj.bias, residual=x2),
+                                         lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, save=False)
+            q = ops.linear_fwd(x2, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
+            kv = ops.linear_fwd(mem2, ca.in_proj_weight[E:], ca.in_proj_bias[E:])      # [(B*L)][2E]
+            o, _ = ops.attention_fwd(q, 0, E, kv, 0, 2 * E, kv, E, 2 * E, B, H, T, L, E // H, False)
+            x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, ca.out_proj.weight, ca.out_proj.bias, residual=x2),
+                                         lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, save=False)
+            h = ops.linear_fwd(x2, lyr.linear1.weight, lyr.linear1.bias, act=ACT_RELU)
+            x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(h, lyr.linear2.weight, lyr.linear2.bias, residual=x2),
+                                         lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, save=False)
+        xn, _, _ = ops.layernorm_fwd(x2, self.pre_output_norm.weight, self.pre_output_norm.bias, self.pre_output_norm.eps,
+                                     save=False)
+        logits = ops.empty(T, B, V, device=memory.device)
+        # rows of xn are (b,t); batch the GEMM over b so that C[t][b][:] is written in place (no transpose pass)
+        ops.gemm_raw(ops.OP_NT, xn.data_ptr(), self.fc_out.weight.data_ptr(), logits.data_ptr(), T, V, E, E, E, B * V,
+                     bias=self.fc_out.bias.data_ptr(), batch=(B, 1), strides=(T * E, 0, 0, 0, V, 0))
+        return logits
+
+    @torch.no_grad()
+    def forward(self, images, captions):
+        memory = self.project_memory(self.encoder.forward_features(images))
+        return self.decode(memory, captions)
+
+    def caption_image(self, image, vocabulary, max_length: int = 20, beam_size: int = 5, length_penalty: float = 0.6,
+                      early_stopping: bool = True, num_return_sequences: int = 1):
+        raise NotImplementedError("beam-search captioning (reference :108-252) is SURVEY.md §8(f) row N1, scheduled after "
+                                  "the KD step; not part of the train-step hot path")

@@ -1,0 +1,269 @@
+"""The KD train step, MI355X-native — the loop body of the reference's train_student_with_kd()
+(/root/reference/src/train_student_kd.py:258-303) as a reusable object, plus what the reference lacks:
+data-parallel replication over one 8xMI355X node with ONE RCCL all-reduce of the flat gradient buffer.
+
+Design (MI355X-first):
+  * every trainable tensor (student layer3/4 + projection + refinement + decoder, encoder projector) is a
+    VIEW into one flat fp32 parameter buffer; `.grad`s are views into one flat gradient buffer; Adam moments
+    are flat too.  Gradient norm = one streaming reduction, AdamW = one fused pass per LR group (28 B/param),
+    gradient exchange = one all-reduce of 120 MB over xGMI — no per-tensor launches.
+  * forward + loss + backward is captured once into a hipGraph (torch.cuda.CUDAGraph) and replayed: the ~1.5k
+    kernel launches of a step cost one graph launch on the host; so is the clip+AdamW tail.  The all-reduce
+    runs between the two graphs on the same stream.
+  * all-reduce happens BEFORE clipping, so every rank derives the same norm and takes the same step with no
+    further communication; equal per-rank batches make SUM/world exact for the KL / MSE / cosine terms.
+  * the LR schedule (CosineAnnealingWarmRestarts T_0=5, T_mult=2, eta_min=1e-6, fractional-epoch stepping,
+    reference :236,:303) and Adam bias corrections live in a small device buffer updated per step, so the
+    captured optimizer graph follows the schedule.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import nn as hnn
+from . import ops
+from .distillation_utils import DistillationLoss, TeacherWrapper
+
+
+def cosine_warm_restarts_factor(epoch: float, T_0: int = 5, T_mult: int = 2) -> float:
+    """(1 + cos(pi * T_cur / T_i)) / 2 of torch.optim.lr_scheduler.CosineAnnealingWarmRestarts.step(epoch), closed form
+    for fractional epochs; a group's LR is eta_min + (base_lr - eta_min) * factor."""
+    if epoch >= T_0:
+        if T_mult == 1:
+            t_cur, t_i = epoch % T_0, T_0
+        else:
+            n = int(math.log(epoch / T_0 * (T_mult - 1) + 1, T_mult))
+            t_cur = epoch - T_0 * (T_mult ** n - 1) / (T_mult - 1)
+            t_i = T_0 * T_mult ** n
+    else:
+        t_cur, t_i = epoch, T_0
+    return (1 + math.cos(math.pi * t_cur / t_i)) / 2
+
+
+class FlatParams:
+    """Re-homes a list of parameter groups into flat fp32 buffers (params, grads) + Adam moments."""
+
+    def __init__(self, groups: List[Tuple[str, List[nn.Parameter]]], device):
+        self.segments: List[Tuple[str, int, int]] = []           # (name, start, end) in elements
+        metas = []
+        off = 0
+        seen = set()
+        for name, plist in groups:
+            start = off
+            for p in plist:
+                if not p.requires_grad or id(p) in seen:
+                    continue
+                seen.add(id(p))
+                n = p.numel()
+                metas.append((p, off, n))
+                off += (n + 3) // 4 * 4                           # keep every tensor 16-byte aligned
+            self.segments.append((name, start, off))
+        self.total = off
+        self.param = torch.zeros(off, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=device)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=device)
+        with torch.no_grad():
+            for p, o, n in metas:
+                if p.dim() == 4:                                  # conv weight: physical [Cout][R][S][Cin]
+                    co, ci, r, s = p.shape
+                    view = self.param[o:o + n].view(co, r, s, ci).permute(0, 3, 1, 2)
+                    gview = self.grad[o:o + n].view(co, r, s, ci).permute(0, 3, 1, 2)
+                else:
+                    view = self.param[o:o + n].view(p.shape)
+                    gview = self.grad[o:o + n].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = gview
+        self.metas = metas
+
+    def segment(self, name: str) -> Tuple[int, int]:
+        for n, a, b in self.segments:
+            if n == name:
+                return a, b
+        raise KeyError(name)
+
+
+class KDTrainer:
+    """One object = the reference's training-loop state: models, loss, optimizer state, schedule."""
+
+    def __init__(self, student, teacher, projectors: Dict[str, nn.Module], *, vocab_size: int, alpha=0.7, beta=0.2,
+                 gamma=0.1, temperature=4.0, learning_rate=2e-4, weight_decay=0.01, max_norm=1.0, batches_per_epoch=1000,
+                 batch_size: int = 64, t_plus_1: int = 16, use_graph: bool = True, process_group=None):
+        self.student, self.teacher, self.projectors = student, teacher, projectors
+        self.device = next(student.parameters()).device
+        self.teacher_wrapper = TeacherWrapper(teacher)
+        self.loss = DistillationLoss(alpha, beta, gamma, temperature, vocab_size)
+        self.loss.unit_grad_fastpath = True
+        self.lr, self.wd, self.max_norm = learning_rate, weight_decay, max_norm
+        self.betas, self.eps = (0.9, 0.999), 1e-8
+        self.batches_per_epoch = batches_per_epoch
+        self.pg = process_group
+        self.world = torch.distributed.get_world_size(process_group) if (process_group is not None or
+                                                                          torch.distributed.is_initialized()) else 1
+        # LR groups exactly as train_student_kd.py:219-234 (encoder lr x0.1; decoder; refinement + projectors)
+        other = list(student.attention_refinement.parameters()) if student.use_attention_refinement else []
+        proj_params = [p for pr in projectors.values() for p in pr.parameters()]
+        self.flat = FlatParams([("encoder", list(student.encoder.parameters())), ("decoder", list(student.decoder.parameters())),
+                                ("refine", other), ("projector", proj_params)], self.device)
+        self.group_lr_mult = {"encoder": 0.1, "decoder": 1.0, "refine": 1.0, "projector": 1.0}
+        self.hyper = torch.zeros(4, 4, dtype=torch.float32, device=self.device)     # per group: lr, 1-b1^t, 1-b2^t, -
+        self.hyper_host = torch.zeros(4, 4, dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.zeros(4, 4)
+        self.norms = torch.zeros(2, dtype=torch.float32, device=self.device)        # [student norm, projector norm]
+        self.ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
+        self.step_count = 0
+        self.batch_idx = 0
+        self.epoch = 0
+        self.drop_step = torch.zeros(1, dtype=torch.int64, device=self.device)
+        ops.set_dropout_step_counter(self.drop_step)
+        self.images = torch.zeros(batch_size, 3, 224, 224, dtype=torch.float32, device=self.device)
+        self.captions = torch.zeros(t_plus_1, batch_size, dtype=torch.int64, device=self.device)
+        self.out5 = None
+        self.use_graph = use_graph and self.device.type == "cuda"
+        self.g_fb: Optional[torch.cuda.CUDAGraph] = None
+        self.g_opt: Optional[torch.cuda.CUDAGraph] = None
+
+    # ------------------------------------------------------------------ the step body
+    def _forward_backward(self):
+        """teacher fwd (no grad, fp32) -> student fwd -> projector -> KD loss -> backward  (reference :262-288)."""
+        self.flat.grad.zero_()
+        self.drop_step += 1
+        cin, ctg = self.captions[:-1], self.captions[1:]
+        t_out = self.teacher_wrapper(self.images, cin)
+        logits, enc, hids, _ = self.student(self.images, cin)
+        s_out = {"logits": logits, "encoder_features": enc, "hidden_states": hids}
+        t_out["encoder_features"] = self.projectors["encoder"](t_out["encoder_features"])
+        out5 = self.loss.forward_device(s_out, t_out, ctg)
+        out5[0].backward()
+        self.out5 = out5
+        return out5
+
+    def _optimizer(self):
+        """clip_grad_norm_(student, 1.0); clip per projector; AdamW (reference :292-299), fused over the flat buffers.
+        Gradients hold the SUM over ranks at this point; 1/world is folded into the kernels."""
+        f = self.flat
+        inv = 1.0 / self.world
+        a0, _ = f.segment("encoder")
+        _, b2 = f.segment("refine")
+        pa, pb = f.segment("projector")
+        ops.grad_norm(f.grad[a0:b2], self.ws, self.norms[0:1])
+        if pb > pa:
+            ops.grad_norm(f.grad[pa:pb], self.ws, self.norms[1:2])
+        for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
+            a, b = f.segment(name)
+            if b <= a:
+                continue
+            norm = self.norms[1:2] if name == "projector" else self.norms[0:1]
+            ops.adamw_step(f.param[a:b], f.grad[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], 0.0, self.betas, self.eps, self.wd, 0,
+                           norm=norm, max_norm=self.max_norm, inv_scale=inv, hyper=self.hyper[gi])
+
+    def _update_hyper(self):
+        t = self.step_count + 1
+        ep = self.epoch + self.batch_idx / max(1, self.batches_per_epoch)
+        for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
+            # the scheduler is stepped AFTER optimizer.step() in the reference (:299-303): step k uses the LR set at k-1
+            base = self.lr * self.group_lr_mult[name]
+            self.hyper_host[gi, 0] = self.eta_min + (base - self.eta_min) * self._f_now
+            self.hyper_host[gi, 1] = 1.0 - self.betas[0] ** t
+            self.hyper_host[gi, 2] = 1.0 - self.betas[1] ** t
+        self.hyper.copy_(self.hyper_host, non_blocking=True)
+        self._f_next = cosine_warm_restarts_factor(ep)
+
+    _f_now = 1.0
+    _f_next = 1.0
+    eta_min = 1e-6
+
+    def _capture(self):
+        bufs = [(b, b.clone()) for b in self.student.buffers()]       # warm-up must not count as training steps
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):                                    # warm-up: allocator, lazy inits, BN counters
+                self._forward_backward()
+                self._optimizer_dry()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.g_fb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_fb):
+            self._forward_backward()
+        self.g_opt = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_opt):
+            self._optimizer()
+        with torch.no_grad():
+            for b, saved in bufs:
+                b.copy_(saved)
+            self.drop_step.zero_()
+
+    def _optimizer_dry(self):
+        """warm-up call of the optimizer kernels that leaves parameters untouched (lr = 0, moments restored)."""
+        self.hyper.zero_()
+        self.hyper[:, 1:3] = 1.0
+        m, v = self.flat.exp_avg.clone(), self.flat.exp_avg_sq.clone()
+        wd, self.wd = self.wd, 0.0
+        self._optimizer()
+        self.wd = wd
+        self.flat.exp_avg.copy_(m)
+        self.flat.exp_avg_sq.copy_(v)
+
+    # ------------------------------------------------------------------ public
+    def train_step(self, images: Optional[torch.Tensor] = None, captions: Optional[torch.Tensor] = None):
+        """One KD step on this rank's batch.  Returns out5 (device tensor: total, ce, token_kd, feature_kd, hidden_kd)
+        without synchronising.  images (B,3,224,224) fp32, captions (T+1,B) int64; None = reuse the resident batch."""
+        if images is not None:
+            self.images.copy_(images, non_blocking=True)
+        if captions is not None:
+            self.captions.copy_(captions, non_blocking=True)
+        self.student.train()
+        if self.use_graph and self.g_fb is None:
+            self._capture()
+        self._update_hyper()
+        if self.use_graph:
+            self.g_fb.replay()
+        else:
+            self._forward_backward()
+        if self.world > 1:
+            torch.distributed.all_reduce(self.flat.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+        if self.use_graph:
+            self.g_opt.replay()
+        else:
+            self._optimizer()
+        self.step_count += 1
+        self.batch_idx += 1
+        self._f_now = self._f_next
+        if self.batch_idx >= self.batches_per_epoch:
+            self.batch_idx = 0
+            self.epoch += 1
+        return self.out5
+
+    def loss_dict(self) -> Dict[str, float]:
+        v = self.out5.detach().cpu().tolist()
+        return {"total_loss": v[0], "ce_loss": v[1], "token_kd_loss": v[2], "feature_kd_loss": v[3], "hidden_kd_loss": v[4]}
+
+
+def build_kd_models(vocab_size=5000, embed_size=256, hidden_size=512, num_layers=2, dropout=0.3, refine=True,
+                    teacher_embed=512, teacher_heads=8, teacher_layers=4, teacher_dropout=0.15, device="cuda", seeds=(0, 1, 2)):
+    """cfg3 of BASELINE.json: the student/teacher/projector triple with the values hard-coded at
+    /root/reference/src/train_student_kd.py:98-101,161-167, key-seeded weights (no pretrained weights offline)."""
+    from .distillation_utils import create_feature_projectors
+    from .student_model import CaptioningStudent
+    from .teacher_model import CaptioningTeacher
+    from .utils.seeded_init import apply_seeded_init
+    import contextlib
+    import io
+    student = CaptioningStudent(vocab_size, embed_size, hidden_size, num_layers, dropout, refine)
+    teacher = CaptioningTeacher(vocab_size, teacher_embed, teacher_heads, teacher_layers, teacher_dropout)
+    apply_seeded_init(student, seeds[0])
+    apply_seeded_init(teacher, seeds[1])
+    teacher.eval()
+    with contextlib.redirect_stdout(io.StringIO()):
+        projectors = create_feature_projectors(teacher, student)
+    apply_seeded_init(projectors["encoder"], seeds[2])
+    student.to(device)
+    teacher.to(device)
+    for k in projectors:
+        projectors[k].to(device)
+    return student, teacher, projectors

@@ -55,8 +55,8 @@ typedef struct IckGemm {
   const float* A; const float* B; float* C;
   const float* bias;       /* [N] or NULL */
   const float* residual;   /* [M][ldr] or NULL, same batch strides as C */
-  float* stat_sum;         /* [N] or NULL: += column sums of the raw (pre-activation) product (BatchNorm batch stats) */
-  float* stat_sq;          /* [N] or NULL: += column sums of squares */
+  double* stat_sum;        /* [N] or NULL: += column sums of the raw (pre-activation) product (BatchNorm batch stats), fp64 accumulators */
+  double* stat_sq;         /* [N] or NULL: += column sums of squares (fp64) */
   int32_t op, act;
   int32_t M, N, K;
   int64_t lda, ldb, ldc, ldr;
@@ -80,7 +80,7 @@ int ick_vit_assemble(const float* patch, const float* cls, const float* pos, flo
 /* ------------------------------------------------------------------ BatchNorm2d over NHWC rows [M = B*H*W][C]
  * nn.BatchNorm2d inside torchvision resnet50 (student_model.py:16-20,57); train mode = batch statistics + running-stat
  * update, also for the "frozen" stem.  Batch sums come from the conv epilogue (IckGemm.stat_*). */
-int ick_bn_finalize(const float* sum, const float* sq, float count, const float* gamma, const float* beta,
+int ick_bn_finalize(const double* sum, const double* sq, float count, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
 int ick_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
@@ -110,6 +110,44 @@ int ick_embedding_fwd(const int64_t* ids, const float* table, const float* pe, f
 int ick_embedding_bwd(const int64_t* ids, const float* dout, float* dtable, int64_t n, int D, void* stream);
 int ick_token_pool_fwd(const float* x, float* y, int B, int L, int Lo, int D, void* stream); /* nn.AdaptiveAvgPool1d over tokens (distillation_utils.py:229,246-250) */
 int ick_token_pool_bwd(const float* dy, float* dx, int B, int L, int Lo, int D, void* stream);
+int ick_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, const int64_t* step, void* stream);  /* nn.Dropout; the same call on dy regenerates the mask for backward; *step (device, optional) varies the mask per replayed graph step */
+
+/* ------------------------------------------------------------------ student decoder step (LSTM + spatial attention)
+ * LSTMDecoder.attention_mechanism (student_model.py:173-203) with the time-invariant half hoisted:
+ * W_a [h ; f_j] + b_a = hW[b] + Uf[b][j], Uf = feats W_f^T + b_a (one GEMM per batch), hW = h_top W_h^T (per step). */
+int ick_attn_step_fwd(const float* Uf, const float* hW, const float* feats, float* w_out, float* ctx,
+                      int B, int L, int E, void* stream);                                 /* scores=sum_e tanh(.), softmax_j, ctx=sum_j w_j f_j */
+int ick_attn_step_bwd(const float* dctx, const float* w, const float* Uf, const float* hW, const float* feats,
+                      float* dUf, float* dfeats, float* dhW, int B, int L, int E, void* stream); /* dUf, dfeats accumulated in place (+=) */
+/* one nn.LSTM layer step after the two gate GEMMs (student_model.py:142-148,:244), gate order i,f,g,o */
+int ick_lstm_cell_fwd(const float* G, const float* b_ih, const float* b_hh, const float* c_prev, float* gates,
+                      float* c_out, float* h_out, int B, int H, void* stream);
+int ick_lstm_cell_bwd(const float* dh_a, const float* dh_b, const float* dc_in, const float* gates, const float* c,
+                      const float* c_prev, float* dG, float* dc_prev, int B, int H, void* stream);
+int ick_argmax_rows(const float* x, int64_t* ids, int64_t rows, int V, int64_t ld, void* stream); /* greedy token (student_model.py:369) */
+
+/* ------------------------------------------------------------------ KD losses, fused forward + backward
+ * DistillationLoss (distillation_utils.py:8-200).  Gradients are produced in the same pass as the loss terms,
+ * already multiplied by the caller's weights; ick_kd_combine reduces deterministically into
+ * out5 = {total, ce, token_kd, feature_kd, hidden_kd} (the loss_dict order, :192-198). */
+int ick_count_valid(const int64_t* targets, int n, int* out, void* stream);               /* #targets != PAD(0) (CrossEntropyLoss ignore_index=0, :22) */
+int ick_token_kd_ce(const float* s, const float* t, const int64_t* targets, float* ds, float* row_kl, float* row_ce,
+                    const int* n_valid, int rows, int V, float tau, float g_kd, float g_ce_num, void* stream); /* :30-54 + :154 */
+int ick_feature_kd(const float* s, const float* t, float* ds, float* dt, float* part, int B, int L, int E, float gscale,
+                   void* stream);                                                         /* :56-94 */
+int ick_hidden_kd(const float* s, const float* t, float* ds, float* part, int steps, int B, int H, float gscale,
+                  void* stream);                                                          /* :96-136 */
+int ick_kd_combine(const float* row_kl, const float* row_ce, int rows, const int* n_valid, const float* feat_part, int Bf,
+                   int Ef, const float* hid_part, int hid_steps, int hid_B, int hid_H, float w_ce, float alpha, float beta,
+                   float gamma, float tau, float* out5, void* stream);                    /* :184-189 */
+int ick_scale_by_scalar(float* x, const float* scalar, int64_t n, void* stream);          /* x *= *scalar (device scalar) */
+
+/* ------------------------------------------------------------------ optimizer tail (train_student_kd.py:292-299)
+ * flat fp32 buffers; clip_grad_norm_(max_norm) folded into the AdamW pass through the device-resident norm. */
+int ick_grad_norm(const float* x, int64_t n, float* workspace, float* norm_out, int accumulate, void* stream);
+int ick_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, int step, const float* norm, float max_norm, float inv_scale, int write_clipped,
+                   const float* hyper, void* stream);
 
 #ifdef __cplusplus
 }

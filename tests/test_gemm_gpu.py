@@ -107,7 +107,7 @@ def test_conv_fwd_dgrad_wgrad(ops, Nb, H, W, Cin, Cout, R, stride, pad):
     w = rnd(Cout, Cin, R, R, seed=2, scale=1.0 / math.sqrt(Cin * R * R))
     xd = x.cuda().permute(0, 2, 3, 1).contiguous()          # NHWC
     wd = w.cuda().permute(0, 2, 3, 1).contiguous()          # (Cout,R,S,Cin)
-    stats = torch.zeros(2, Cout, device="cuda")
+    stats = torch.zeros(2, Cout, device="cuda", dtype=torch.float64)
     y = ops.conv_fwd(xd, wd, stride, pad, stats=(stats[0], stats[1]))
     ref = F.conv2d(x.double(), w.double(), None, stride, pad)
     assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL
@@ -133,7 +133,7 @@ def test_conv_stem_c4(ops):
     assert torch.equal(x4[..., :3].cpu(), x.permute(0, 2, 3, 1)) and x4[..., 3].abs().max().item() == 0
     w4 = torch.zeros(64, 7, 7, 4, device="cuda")
     w4[..., :3] = w.cuda().permute(0, 2, 3, 1)
-    stats = torch.zeros(2, 64, device="cuda")
+    stats = torch.zeros(2, 64, device="cuda", dtype=torch.float64)
     y = ops.conv_fwd(x4, w4, 2, 3, stats=(stats[0], stats[1]))
     ref = F.conv2d(x.double(), w.double(), None, 2, 3)
     assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL

@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Diagnostic (GPU box): per-tensor gradient error of the HIP KD step vs an fp64 CPU oracle, next to the error of
+the fp32 CPU oracle (the reference's own arithmetic class) vs the same fp64 run."""
+import sys, os
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import restatement as R
+from imagecaptioner_amd.utils.seeded_init import seeded_state_dict, synthetic_batch
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+
+def run_cpu(dtype):
+    torch.set_default_dtype(dtype)
+    trainable = lambda k: not any(k.startswith(f"encoder.resnet.{i}.") for i in (0, 1, 4, 5)) and "running_" not in k
+    conv = lambda sd: {k: (v.to(dtype).clone().requires_grad_(True) if (v.dtype.is_floating_point and trainable(k)) else v.to(dtype).clone()) for k, v in sd.items()}
+    ssd = conv(seeded_state_dict(R.student_state_shapes(5000, 256, 512, 2, True), seed=0))
+    tsd = {k: v.to(dtype) for k, v in seeded_state_dict(R.teacher_state_shapes(5000, 512, 4), seed=1).items()}
+    psd = conv(seeded_state_dict(R.projector_state_shapes(512, 256), seed=2))
+    images, caps = synthetic_batch(B, 5000, 16, seed=1234)
+    R.kd_forward_backward(ssd, tsd, psd, images.to(dtype), caps, hidden=512, layers=2, refine=True, t_heads=8, t_layers=4)
+    torch.set_default_dtype(torch.float32)
+    return {k: v.grad.double() for k, v in ssd.items() if v.grad is not None}
+
+g64 = run_cpu(torch.float64)
+g32 = run_cpu(torch.float32)
+
+from imagecaptioner_amd.train_student_kd import build_kd_models
+from imagecaptioner_amd.distillation_utils import DistillationLoss, TeacherWrapper
+student, teacher, projectors = build_kd_models(device="cuda")
+for m in list(student.modules()) + list(projectors["encoder"].modules()):
+    if isinstance(m, torch.nn.Dropout):
+        m.p = 0.0
+student.attention_refinement.attention.dropout = 0.0
+student.decoder.lstm.dropout = 0.0
+student.train()
+images, caps = synthetic_batch(B, 5000, 16, seed=1234)
+images, caps = images.cuda(), caps.cuda()
+t_out = TeacherWrapper(teacher)(images, caps[:-1])
+logits, enc, hids, _ = student(images, caps[:-1])
+t_out["encoder_features"] = projectors["encoder"](t_out["encoder_features"])
+loss, parts = DistillationLoss(0.7, 0.2, 0.1, 4.0, 5000)({"logits": logits, "encoder_features": enc, "hidden_states": hids}, t_out, caps[1:])
+loss.backward()
+print(parts)
+rows = []
+for k, p in student.named_parameters():
+    if p.grad is None:
+        continue
+    a = p.grad.detach().double().cpu(); r = g64[k]; c = g32[k]
+    l2 = lambda x, y: ((x - y).norm() / y.norm().clamp_min(1e-30)).item()
+    mx = lambda x, y: ((x - y).abs().max() / y.abs().max().clamp_min(1e-30)).item()
+    rows.append((k, l2(a, r), l2(c, r), mx(a, r), mx(c, r)))
+print(f"{'tensor':60s} {'hip L2':>9s} {'cpu32 L2':>9s} {'hip max':>9s} {'cpu32 max':>9s}")
+for k, a, c, am, cm in rows:
+    flag = "  <<<" if a > 3 * max(c, 1e-5) and a > 1e-3 else ""
+    print(f"{k:60s} {a:9.2e} {c:9.2e} {am:9.2e} {cm:9.2e}{flag}")
