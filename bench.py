@@ -42,6 +42,13 @@ def cpu_baseline(batch: int = 16):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:                                    # cgroup CPU quota, when the box sets one
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(p))))
+    except Exception:
+        pass
+    cores = min(cores, 16)                  # a one-GPU box's CPU share (more threads than that only oversubscribe)
     torch.set_num_threads(cores)
     trainable = lambda k: not any(k.startswith(f"encoder.resnet.{i}.") for i in (0, 1, 4, 5)) and "running_" not in k
     mk = lambda sd: {k: (v.clone().requires_grad_(True) if (v.dtype.is_floating_point and trainable(k)) else v.clone())

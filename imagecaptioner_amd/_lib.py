@@ -12,6 +12,12 @@ import os
 import re
 from typing import Dict, List, Tuple
 
+# torch bundles its own libamdhip64.so.7 / libhsa-runtime64 and loads them by path.  Importing torch FIRST makes
+# libick.so's DT_NEEDED libamdhip64.so.7 resolve to that already-loaded runtime; the other order puts two HIP
+# runtimes in one process and launches fail with hipErrorNoDevice.  (A non-torch C-ABI consumer simply gets
+# /opt/rocm's runtime.)
+import torch  # noqa: F401  (load order matters)
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libick.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "ick.h")
