@@ -1,0 +1,37 @@
+"""Data-parallel gradient exchange for the KD step: ONE all-reduce(SUM) of the flat fp32 gradient buffer per
+optimizer step, one process per GPU, `torch.distributed` backend "nccl" (= RCCL over xGMI on ROCm; "gloo" in the
+CPU tests).  The reference has no distributed code at all — this is the build-side addition.
+
+Why a single flat all-reduce and not bucketed overlap (yet): the payload is 120 MB; a direct reduce-scatter +
+all-gather over the fully connected xGMI mesh moves S/8 per peer link per phase (~0.2 ms), a ring ~1.4 ms
+(SURVEY.md §5), against a ~45 ms step.  1/world is NOT applied here: it is folded into the fused clip+AdamW
+kernels (csrc/optim.hip inv_scale), which saves one pass over the buffer.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def world_size(group=None) -> int:
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def allreduce_gradients(flat_grad: torch.Tensor, group=None) -> torch.Tensor:
+    """In-place SUM over ranks of the flat gradient buffer (no-op for a single process).  Every rank then holds the
+    same sum, so the norm, the clip coefficient and the AdamW update are identical everywhere with no further
+    communication (all-reduce BEFORE clipping)."""
+    if world_size(group) > 1:
+        dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM, group=group)
+    return flat_grad
+
+
+def shard_batch(global_batch: int, rank: int, world: int):
+    """Contiguous, equal shards of the global batch (512 -> 8 x 64): equal sizes are what make
+    mean-over-global-batch == mean of per-rank means for the KL / MSE / cosine terms."""
+    if global_batch % world != 0:
+        raise ValueError(f"global batch {global_batch} is not divisible by world size {world}")
+    per = global_batch // world
+    return rank * per, (rank + 1) * per

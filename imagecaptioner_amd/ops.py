@@ -404,22 +404,47 @@ def argmax_rows(x: torch.Tensor) -> torch.Tensor:
     return ids
 
 
+def _skinny_splitk(M: int, N: int, K: int) -> int:
+    """Split-K factor for GEMV-sized products (M <= 64 rows, the per-token decoder step): with one 64x64 tile per
+    64 output columns only N/64 workgroups exist, each serially walking all of K; splitting K spreads the weight
+    read over ~256 CUs (fp32 atomics into a zeroed / accumulating output)."""
+    if M > 64:
+        return 1
+    tiles = (N + 63) // 64
+    return max(1, min(K // 32, 256 // max(tiles, 1)))
+
+
 def gemm_nt(x: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Tensor, *, bias=None, residual=None,
-            accumulate=False, act=ACT_NONE, splitk: int = 1):
+            accumulate=False, act=ACT_NONE, splitk: int = 0):
     """out (M,N) = act(x (M,K) @ W^T + bias) [+ residual]; W given by raw pointer + row pitch (column slices of a
     wider weight, e.g. the W_h / W_f halves of the decoder's attention matrix)."""
     M = x.numel() // K
-    gemm_raw(OP_NT, x.data_ptr(), w_ptr, out.data_ptr(), M, N, K, K, ldb, N, bias=_ptr(bias), residual=_ptr(residual),
-             ldr=N, act=act, accumulate=accumulate, splitk=splitk)
+    if splitk <= 0:
+        splitk = _skinny_splitk(M, N, K) if act == ACT_NONE else 1
+    if splitk > 1:
+        if not accumulate:
+            out.zero_()
+        gemm_raw(OP_NT, x.data_ptr(), w_ptr, out.data_ptr(), M, N, K, K, ldb, N, bias=_ptr(bias), residual=_ptr(residual),
+                 ldr=N, splitk=splitk)
+    else:
+        gemm_raw(OP_NT, x.data_ptr(), w_ptr, out.data_ptr(), M, N, K, K, ldb, N, bias=_ptr(bias), residual=_ptr(residual),
+                 ldr=N, act=act, accumulate=accumulate)
     return out
 
 
 def gemm_nn(dy: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Tensor, *, residual=None,
-            accumulate=False):
+            accumulate=False, splitk: int = 0):
     """out (M,K) = dy (M,N) @ W (N,K) [+ residual]; W by raw pointer with row pitch ldb."""
     M = dy.numel() // N
-    gemm_raw(OP_NN, dy.data_ptr(), w_ptr, out.data_ptr(), M, K, N, N, ldb, K, residual=_ptr(residual), ldr=K,
-             accumulate=accumulate)
+    if splitk <= 0:
+        splitk = _skinny_splitk(M, K, N)
+    if splitk > 1:
+        if not accumulate:
+            out.zero_()
+        gemm_raw(OP_NN, dy.data_ptr(), w_ptr, out.data_ptr(), M, K, N, N, ldb, K, residual=_ptr(residual), ldr=K, splitk=splitk)
+    else:
+        gemm_raw(OP_NN, dy.data_ptr(), w_ptr, out.data_ptr(), M, K, N, N, ldb, K, residual=_ptr(residual), ldr=K,
+                 accumulate=accumulate)
     return out
 
 

@@ -24,6 +24,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
+from . import dp
 from . import nn as hnn
 from . import ops
 from .distillation_utils import DistillationLoss, TeacherWrapper
@@ -226,7 +227,7 @@ class KDTrainer:
         else:
             self._forward_backward()
         if self.world > 1:
-            torch.distributed.all_reduce(self.flat.grad, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            dp.allreduce_gradients(self.flat.grad, self.pg)
         if self.use_graph:
             self.g_opt.replay()
         else:

@@ -1,0 +1,181 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol include/ick.h declares, argument
+validation happens before any HIP call, the host logic (schedule, flat buffers, seeded init, API surface)
+behaves like the reference's, and the product path refuses to run without the GPU (no silent fallback)."""
+import ctypes
+import io
+import contextlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+def test_header_symbols_are_exported():
+    from imagecaptioner_amd import _lib
+    protos = _lib.parse_header()
+    assert len(protos) >= 35 and "ick_gemm_f32" in protos and "ick_token_kd_ce" in protos
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in protos:
+        assert hasattr(L, name), f"libick.so does not export {name} declared in include/ick.h"
+    assert _lib.lib().ick_abi_version() == 1
+    # every extern "C" entry of the sources is declared in the header (no undeclared ABI)
+    import glob
+    import re
+    defined = set()
+    for f in glob.glob(os.path.join(ROOT, "imagecaptioner_amd", "csrc", "*.hip")):
+        defined |= set(re.findall(r"^(?:extern \"C\" )?(?:int|const char\*) (ick_\w+)\(", open(f).read(), flags=re.M))
+    assert defined == set(protos), (defined ^ set(protos))
+
+
+def test_argument_validation_needs_no_gpu():
+    from imagecaptioner_amd import _lib
+    L = _lib.lib()
+    assert L.ick_gemm_f32(None, None) < 0
+    assert b"null descriptor" in L.ick_last_error()
+    d = _lib.IckGemm()
+    d.A, d.B, d.C = 16, 16, 16
+    d.M, d.N, d.K = 4, 4, 0
+    assert L.ick_gemm_f32(ctypes.byref(d), None) < 0 and b"empty problem" in L.ick_last_error()
+    d.K, d.op, d.lda, d.ldb = 6, _lib.OP_NT, 6, 8
+    assert L.ick_gemm_f32(ctypes.byref(d), None) < 0 and b"multiples of 4" in L.ick_last_error()
+    assert L.ick_layernorm_fwd(16, 16, 16, 16, None, None, 4, 6, 1e-5, None) < 0      # D % 4
+    assert L.ick_token_kd_ce(16, 16, None, 16, 16, 16, 16, 4, 30000, 4.0, 1.0, 0.0, None) < 0
+    assert b"too large" in L.ick_last_error()
+    with pytest.raises(_lib.IckError):
+        _lib.check(L.ick_adamw_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 0.0, 1, None, 1.0, 1.0, 0, None, None))
+
+
+def test_gemm_struct_layout_matches_header():
+    from imagecaptioner_amd import _lib
+    # field order of the ctypes mirror == field order in the header's struct
+    import re
+    src = open(_lib.HEADER).read()
+    body = src[src.index("typedef struct IckGemm {"):src.index("} IckGemm;")]
+    body = re.sub(r"/\*.*?\*/", " ", body, flags=re.S)
+    names = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        parts = decl.replace("*", " ").split()
+        rest = decl.split(None, 2 if parts[0] == "const" else 1)[-1]
+        for nm in rest.split(","):
+            names.append(nm.replace("*", "").strip().split()[-1])
+    assert names == [f[0] for f in _lib.IckGemm._fields_]
+
+
+def test_product_path_refuses_cpu_tensors():
+    from imagecaptioner_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.linear_fwd(torch.zeros(4, 8), torch.zeros(4, 8))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from imagecaptioner_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="There is no CPU fallback"):
+        _lib.lib()
+
+
+def test_cosine_warm_restarts_matches_torch():
+    from imagecaptioner_amd.train_student_kd import cosine_warm_restarts_factor as f
+    p = torch.nn.Parameter(torch.zeros(1))
+    o = torch.optim.SGD([p], lr=2e-4)
+    s = torch.optim.lr_scheduler.CosineAnnealingWarmRestarts(o, T_0=5, T_mult=2, eta_min=1e-6)
+    for ep in np.concatenate([np.linspace(0, 36, 97), [4.999, 5.0, 14.999, 15.0, 35.0]]):
+        s.step(float(ep))
+        assert abs(o.param_groups[0]["lr"] - (1e-6 + (2e-4 - 1e-6) * f(float(ep)))) < 1e-12
+
+
+def test_state_dict_surface_matches_reference_on_cpu():
+    from imagecaptioner_amd.student_model import CaptioningStudent, count_parameters
+    from imagecaptioner_amd.teacher_model import CaptioningTeacher
+    g = load_golden("param_counts.npz")
+    s = CaptioningStudent(3000)
+    assert sorted(s.state_dict().keys()) == sorted(g["student_keys"].tolist())
+    assert count_parameters(s) == (int(g["student_total"]), int(g["student_trainable"]))
+    assert s.encoder.adaptive_pool.output_size == (7, 7) and s.embed_size == 256 and s.hidden_size == 512
+    assert not any(p.requires_grad for n, p in s.named_parameters() if n.startswith("encoder.resnet.5."))
+    assert all(p.requires_grad for n, p in s.named_parameters() if n.startswith("encoder.resnet.6."))
+    t = CaptioningTeacher(3000, embed_size=512, num_heads=8, num_decoder_layers=4, dropout=0.15)
+    assert sorted(t.state_dict().keys()) == sorted(g["teacher_keys"].tolist())
+    assert t.encoder.num_features == 384 and t.encoder_projection.out_features == 512
+    assert getattr(t, "embed_size", 512) == 512          # the reference teacher does not set it either
+    # conv weights keep logical OIHW shapes (state_dict compatible) but live channels_last for the kernels
+    w = s.encoder.resnet[6][0].conv2.weight
+    assert tuple(w.shape) == (256, 256, 3, 3) and w.is_contiguous(memory_format=torch.channels_last)
+    sd = {k: v.clone() for k, v in s.state_dict().items()}
+    s.load_state_dict(sd)
+    assert s.encoder.resnet[6][0].conv2.weight.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_create_feature_projectors_and_helpers():
+    from imagecaptioner_amd import distillation_utils as D
+    from imagecaptioner_amd.student_model import CaptioningStudent
+    from imagecaptioner_amd.teacher_model import CaptioningTeacher
+    s, t = CaptioningStudent(100, 128, 256, 1, use_attention_refinement=False), CaptioningTeacher(100, 512, 8, 1)
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        pr = D.create_feature_projectors(t, s)
+    assert "512 -> 128, seq_len: 197 -> 49" in buf.getvalue()
+    enc = pr["encoder"]
+    assert (enc.teacher_dim, enc.student_dim, enc.teacher_seq_len, enc.student_seq_len) == (512, 128, 197, 49)
+    assert sorted(enc.state_dict()) == ["feature_projection.0.bias", "feature_projection.0.weight",
+                                        "feature_projection.3.bias", "feature_projection.3.weight"]
+    assert isinstance(pr["hidden"].seq_projection, torch.nn.AdaptiveAvgPool1d)      # 197 -> 64 default, never called
+    L = D.DistillationLoss()
+    assert (L.alpha, L.beta, L.gamma, L.temperature, L.vocab_size) == (0.7, 0.2, 0.1, 4.0, None)
+    assert abs((1 - L.alpha - L.beta - L.gamma) - 2.7755575615628914e-17) < 1e-30
+
+    class V:
+        itos = {0: "<PAD>", 1: "<START>", 2: "<END>", 3: "<UNK>", 4: "a", 5: "dog", 6: "runs"}
+    assert D.compute_bleu_score([1, 4, 5, 2, 0], [1, 4, 5, 6, 2], V) == pytest.approx(2 / 3)
+    assert D.compute_bleu_score([4], [0, 1, 2], V) == 0.0
+    out = io.StringIO()
+    with contextlib.redirect_stdout(out):
+        d = dict(total_loss=1.0, ce_loss=2.0, token_kd_loss=3.0, feature_kd_loss=4.0, hidden_kd_loss=0.0)
+        D.log_training_progress(1, 50, d, 1e-4, 100)
+        D.log_training_progress(1, 51, d, 1e-4, 100)
+    assert out.getvalue().count("Token KD: 3.0000") == 1
+    with pytest.raises(NotImplementedError):
+        t.caption_image(torch.zeros(3, 224, 224), V)
+
+
+def test_seeded_init_is_order_independent_and_batch_layout():
+    from imagecaptioner_amd.utils.seeded_init import seeded_state_dict, seeded_tensor, synthetic_batch
+    a = seeded_state_dict({"x.weight": (4, 3), "y.bias": (5,)}, seed=7)
+    b = seeded_state_dict({"y.bias": (5,), "zzz.weight": (2, 2), "x.weight": (4, 3)}, seed=7)
+    assert torch.equal(a["x.weight"], b["x.weight"]) and torch.equal(a["y.bias"], b["y.bias"])
+    assert seeded_tensor("bn.num_batches_tracked", (), 0) is None and seeded_tensor("pos_encoder.pe", (5000, 1, 8), 0) is None
+    assert (seeded_tensor("bn1.running_var", (64,), 0) >= 0.5).all()
+    images, caps = synthetic_batch(5, 5000, 16, seed=1234, rank=3)
+    assert images.shape == (5, 3, 224, 224) and caps.shape == (16, 5) and caps.dtype == torch.int64
+    assert (caps[0] == 1).all()
+    for b_ in range(5):
+        col = caps[:, b_]
+        n = int((col != 0).sum())
+        assert 8 <= n <= 16 and col[n - 1] == 2 and (col[n:] == 0).all() and (col[1:n - 1] >= 4).all()
+    i2, c2 = synthetic_batch(5, 5000, 16, seed=1234, rank=4)
+    assert not torch.equal(images, i2)
+
+
+def test_flat_params_alias_parameters_and_grads():
+    from imagecaptioner_amd.train_student_kd import FlatParams
+    lin = torch.nn.Linear(6, 5)
+    conv_w = torch.nn.Parameter(torch.randn(8, 4, 3, 3).contiguous(memory_format=torch.channels_last))
+    frozen = torch.nn.Parameter(torch.randn(3), requires_grad=False)
+    w0, c0 = lin.weight.detach().clone(), conv_w.detach().clone()
+    fp = FlatParams([("a", [lin.weight, lin.bias, frozen]), ("b", [conv_w, lin.weight])], torch.device("cpu"))
+    assert fp.segments == [("a", 0, 32 + 8), ("b", 40, 40 + 288)] and fp.total == 328
+    assert torch.equal(lin.weight, w0) and torch.equal(conv_w, c0)
+    assert conv_w.is_contiguous(memory_format=torch.channels_last) and conv_w.grad.is_contiguous(memory_format=torch.channels_last)
+    fp.param[0] = 42.0
+    assert lin.weight[0, 0].item() == 42.0
+    conv_w.grad[1, 2, 0, 1] = 3.0        # logical (co=1, ci=2, r=0, s=1) -> physical [co][r][s][ci]
+    assert fp.grad[40 + ((1 * 3 + 0) * 3 + 1) * 4 + 2].item() == 3.0
+    fp.grad.zero_()
+    assert conv_w.grad.abs().sum().item() == 0.0 and frozen.grad is None
