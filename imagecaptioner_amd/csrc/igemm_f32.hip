@@ -19,6 +19,7 @@
 // Global->LDS is software pipelined through registers (issue tile t+1's loads, run tile t's
 // MFMAs, then write t+1 into the other LDS buffer): one barrier per k-tile.
 #include "ick_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -26,6 +27,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;
 constexpr int NT = 256;
+#ifndef ICK_STASH_AT
+#define ICK_STASH_AT 10
+#endif
+constexpr int STASH_AT = ICK_STASH_AT;   // k offset inside a tile after which the next tile is written to LDS
 
 struct P {  // kernel parameters (by value)
   const float* A; const float* B; float* C;
@@ -45,13 +50,18 @@ __host__ __device__ constexpr bool b_kcontig(int op) {
   return op == ICK_OP_NT || op == ICK_OP_CONV_FWD || op == ICK_OP_CONV_FWD_C4;
 }
 
-__device__ __forceinline__ float4 ldg4(const float* p, bool ok) {
-  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+// Branch-free guarded fetch: a lane whose element is out of range reads a valid dummy address and its value is
+// zeroed where it is CONSUMED (the LDS stash), so the 16-byte loads of tile t+1 stay in flight across tile t's MFMAs.
+// (A branchy `ok ? load : 0` makes hipcc emit s_waitcnt vmcnt(0) right behind the loads: load->compute serialised.)
+__device__ __forceinline__ float4 ldg4u(const float* p, bool ok, const float* safe) {
+  return *reinterpret_cast<const float4*>(ok ? p : safe);
 }
-// k-contiguous fetch of elements [k, k+4) of a row whose valid range ends at kend (any kend: the row pitch is a
-// multiple of 4, so the 16-byte load stays inside the row; components past kend are zeroed)
-__device__ __forceinline__ float4 ldg4k(const float* p, bool ok, int k, int kend) {
-  float4 v = ldg4(p, ok && k < kend);
+__device__ __forceinline__ float4 keep_if(float4 v, bool ok) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+// k-contiguous rows whose valid range ends at kend (any kend: the row pitch is a multiple of 4, so the 16-byte load
+// stays inside the row): zero the components at k+1..k+3 that lie past kend
+__device__ __forceinline__ float4 ktail(float4 v, int k, int kend) {
   if (k + 3 >= kend) {
     if (k + 1 >= kend) v.y = 0.f;
     if (k + 2 >= kend) v.z = 0.f;
@@ -148,13 +158,19 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
   }
 
   float4 ra[PA], rb[PB];
+  unsigned amask = 0, bmask = 0;   // bit i: fetch i of the tile in flight is in range
 
   auto fetch = [&](int kt) {
     const int k0 = kbeg + kt * BK;
+    amask = 0; bmask = 0;
     // ---- A
     if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
 #pragma unroll
-      for (int i = 0; i < PA; ++i) ra[i] = ldg4k(a_ptr[i] + k0, a_ok[i], k0 + a_k4, kend);
+      for (int i = 0; i < PA; ++i) {
+        const bool ok = a_ok[i] && (k0 + a_k4 < kend);
+        amask |= ok ? (1u << i) : 0u;
+        ra[i] = ldg4u(a_ptr[i] + k0, ok, Ag);
+      }
     } else if constexpr (OP == ICK_OP_CONV_FWD) {
       const int tap = k0 / p.Cin; const int ci = k0 - tap * p.Cin + a_k4;
       const int r = tap / p.S, s = tap - r * p.S;
@@ -162,7 +178,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
       for (int i = 0; i < PA; ++i) {
         const int iy = a_y[i] + r, ix = a_x[i] + s;
         const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (k0 + a_k4 < kend);
-        ra[i] = ldg4(a_ptr[i] + ((long)iy * p.W + ix) * p.Cin + ci, ok);
+        amask |= ok ? (1u << i) : 0u;
+        ra[i] = ldg4u(a_ptr[i] + ((long)iy * p.W + ix) * p.Cin + ci, ok, Ag);
       }
     } else if constexpr (OP == ICK_OP_CONV_FWD_C4) {
       const int tap = (k0 + a_k4) >> 2; const int r = tap / p.S, s = tap - r * p.S;
@@ -170,7 +187,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
       for (int i = 0; i < PA; ++i) {
         const int iy = a_y[i] + r, ix = a_x[i] + s;
         const bool ok = a_ok[i] && r < p.R && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        ra[i] = ldg4(a_ptr[i] + ((long)iy * p.W + ix) * 4, ok);
+        amask |= ok ? (1u << i) : 0u;
+        ra[i] = ldg4u(a_ptr[i] + ((long)iy * p.W + ix) * 4, ok, Ag);
       }
     } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
       const int tap = k0 / p.Cout; const int co = k0 - tap * p.Cout + a_k4;
@@ -181,25 +199,34 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
         const int oy = ty / p.stride, ox = tx / p.stride;
         const bool ok = a_ok[i] && ty >= 0 && tx >= 0 && oy * p.stride == ty && ox * p.stride == tx &&
                         oy < p.Ho && ox < p.Wo && (k0 + a_k4 < kend);
-        ra[i] = ldg4(a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co, ok);
+        amask |= ok ? (1u << i) : 0u;
+        ra[i] = ldg4u(a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co, ok, Ag);
       }
     } else {  // A [K][M]
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
         const int k = k0 + a_y[i];
-        ra[i] = ldg4(a_ptr[i] + (long)k * p.lda, a_ok[i] && k < kend);
+        const bool ok = a_ok[i] && k < kend;
+        amask |= ok ? (1u << i) : 0u;
+        ra[i] = ldg4u(a_ptr[i] + (long)k * p.lda, ok, Ag);
       }
     }
     // ---- B
     if constexpr (BKc) {
 #pragma unroll
-      for (int i = 0; i < PB; ++i) rb[i] = ldg4k(b_ptr[i] + k0, b_ok[i], k0 + a_k4, kend);
+      for (int i = 0; i < PB; ++i) {
+        const bool ok = b_ok[i] && (k0 + a_k4 < kend);
+        bmask |= ok ? (1u << i) : 0u;
+        rb[i] = ldg4u(b_ptr[i] + k0, ok, Bg);
+      }
     } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
       const int tap = k0 / p.Cout; const int co0 = k0 - tap * p.Cout;
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int co = co0 + b_y[i];
-        rb[i] = ldg4(b_ptr[i] + ((long)co * p.R * p.S + tap) * p.Cin, b_ok[i] && (k0 + b_y[i] < kend));
+        const bool ok = b_ok[i] && (k0 + b_y[i] < kend);
+        bmask |= ok ? (1u << i) : 0u;
+        rb[i] = ldg4u(b_ptr[i] + ((long)co * p.R * p.S + tap) * p.Cin, ok, Bg);
       }
     } else if constexpr (OP == ICK_OP_CONV_WGRAD) {
       const int hw = p.Ho * p.Wo;
@@ -209,36 +236,45 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
         const int b = k / hw; const int rem = k - b * hw; const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         const int iy = oy * p.stride - p.pad + b_r, ix = ox * p.stride - p.pad + b_s;
         const bool ok = b_ok[i] && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        rb[i] = ldg4(b_ptr[i] + (((long)b * p.H + iy) * p.W + ix) * p.Cin, ok);
+        bmask |= ok ? (1u << i) : 0u;
+        rb[i] = ldg4u(b_ptr[i] + (((long)b * p.H + iy) * p.W + ix) * p.Cin, ok, Bg);
       }
     } else {  // B [K][N]
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int k = k0 + b_y[i];
-        rb[i] = ldg4(b_ptr[i] + (long)k * p.ldb, b_ok[i] && k < kend);
+        const bool ok = b_ok[i] && k < kend;
+        bmask |= ok ? (1u << i) : 0u;
+        rb[i] = ldg4u(b_ptr[i] + (long)k * p.ldb, ok, Bg);
       }
     }
   };
 
-  auto stash = [&](int buf) {
+  // write the fetched tile `kt` into LDS buffer `buf` (zeroing what was out of range)
+  auto stash = [&](int buf, int kt) {
+    const int kq = kbeg + kt * BK + a_k4;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
+      float4 v = keep_if(ra[i], (amask >> i) & 1u);
       if constexpr (AK) {
+        if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) v = ktail(v, kq, kend);
         const int x = i * 64 + (tid >> 2);
-        As[buf][a_k4 + 0][x] = ra[i].x; As[buf][a_k4 + 1][x] = ra[i].y;
-        As[buf][a_k4 + 2][x] = ra[i].z; As[buf][a_k4 + 3][x] = ra[i].w;
+        As[buf][a_k4 + 0][x] = v.x; As[buf][a_k4 + 1][x] = v.y;
+        As[buf][a_k4 + 2][x] = v.z; As[buf][a_k4 + 3][x] = v.w;
       } else {
-        *reinterpret_cast<float4*>(&As[buf][i * A_KR + tid / A_TPK][(tid % A_TPK) * 4]) = ra[i];
+        *reinterpret_cast<float4*>(&As[buf][i * A_KR + tid / A_TPK][(tid % A_TPK) * 4]) = v;
       }
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
+      float4 v = keep_if(rb[i], (bmask >> i) & 1u);
       if constexpr (BKc) {
+        v = ktail(v, kq, kend);
         const int x = i * 64 + (tid >> 2);
-        Bs[buf][a_k4 + 0][x] = rb[i].x; Bs[buf][a_k4 + 1][x] = rb[i].y;
-        Bs[buf][a_k4 + 2][x] = rb[i].z; Bs[buf][a_k4 + 3][x] = rb[i].w;
+        Bs[buf][a_k4 + 0][x] = v.x; Bs[buf][a_k4 + 1][x] = v.y;
+        Bs[buf][a_k4 + 2][x] = v.z; Bs[buf][a_k4 + 3][x] = v.w;
       } else {
-        *reinterpret_cast<float4*>(&Bs[buf][i * B_KR + tid / B_TPK][(tid % B_TPK) * 4]) = rb[i];
+        *reinterpret_cast<float4*>(&Bs[buf][i * B_KR + tid / B_TPK][(tid % B_TPK) * 4]) = v;
       }
     }
   };
@@ -253,7 +289,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
 
   if (nkt > 0) {
     fetch(0);
-    stash(0);
+    stash(0, 0);
   }
   __syncthreads();
 
@@ -263,6 +299,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
     if (kt + 1 < nkt) fetch(kt + 1);
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
+      // the LDS write of tile kt+1 (other buffer: nobody reads it during tile kt) goes in the shadow of the
+      // second half of this tile's MFMAs instead of between the last MFMA and the barrier
+      if (kk == STASH_AT && kt + 1 < nkt) stash(buf ^ 1, kt + 1);
       float av[TM], bv[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) av[i] = As[buf][kk + fk][fa + i * 32];
@@ -274,44 +313,53 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nkt) stash(buf ^ 1);
     __syncthreads();
   }
 
   // ---------------------------------------------------------------- epilogue
-  // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // Interior tiles (the vast majority) take a check-free path; flags are wave-uniform scalars.
   float* __restrict__ Cg = p.C + coff;
-  const float* __restrict__ Rg = p.residual ? p.residual + coff : nullptr;
-  const bool first_split = (split == 0);
+  const float* __restrict__ Rg = (p.residual && split == 0) ? p.residual + coff : nullptr;
+  const float* __restrict__ biasp = (p.bias && split == 0) ? p.bias : nullptr;
+  const int mode = p.splitk > 1 ? 2 : (p.accumulate ? 1 : 0);
+  const int act = p.act;
+  const float alpha = p.alpha;
+  auto epilogue = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int n = n0 + wn * WN + j * 32 + (lane & 31);
-    const bool nok = n < p.N;
-    const float bias = (p.bias && nok && first_split) ? p.bias[n] : 0.f;
-    float ssum = 0.f, ssq = 0.f;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WN + j * 32 + (lane & 31);
+      const bool nok = FULL || n < p.N;
+      const float bias = (biasp && nok) ? biasp[n] : 0.f;
+      float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
+        const int mb = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (m < p.M && nok) {
-          float v = acc[i][j][r] * p.alpha;
-          ssum += v; ssq += v * v;
-          v = act_fn(v + bias, p.act);
-          const long o = (long)m * p.ldc + n;
-          if (Rg && first_split) v += Rg[(long)m * p.ldr + n];
-          if (p.splitk > 1) atomicAdd(Cg + o, v);
-          else if (p.accumulate) Cg[o] += v;
-          else Cg[o] = v;
+        for (int r = 0; r < 16; ++r) {
+          const int m = mb + (r & 3) + 8 * (r >> 2);
+          if (FULL || (m < p.M && nok)) {
+            float v = acc[i][j][r] * alpha;
+            ssum += v; ssq += v * v;
+            v = act_fn(v + bias, act);
+            const long o = (long)m * p.ldc + n;
+            if (Rg) v += Rg[(long)m * p.ldr + n];
+            if (mode == 2) atomicAdd(Cg + o, v);
+            else if (mode == 1) Cg[o] += v;
+            else Cg[o] = v;
+          }
         }
       }
+      if (p.stat_sum) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
+        ssum += __shfl_xor(ssum, 32);
+        ssq += __shfl_xor(ssq, 32);
+        if (lane < 32 && nok) { atomicAdd(p.stat_sum + n, (double)ssum); atomicAdd(p.stat_sq + n, (double)ssq); }
+      }
     }
-    if (p.stat_sum) {  // BatchNorm batch statistics of the raw product
-      ssum += __shfl_xor(ssum, 32);
-      ssq += __shfl_xor(ssq, 32);
-      if (lane < 32 && nok) { atomicAdd(p.stat_sum + n, (double)ssum); atomicAdd(p.stat_sq + n, (double)ssq); }  // fp64: var = E[x^2]-E[x]^2 must not cancel
-    }
-  }
+  };
+  if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
 }
 
 template <int OP, int BM, int BN>
@@ -321,12 +369,30 @@ int launch(const P& p, int nz, hipStream_t st) {
   return ick::launch_status("igemm_f32");
 }
 
+// Tile choice.  fp32 MFMA is slow enough (64 cycles per 32x32x2) that all four tile shapes keep the matrix pipe
+// fed; what separates them on the step's shapes is WAVE QUANTISATION over the 256 CUs: a grid of T workgroups
+// with R resident per CU finishes in ceil(T / 256 / R) * R "slots" of unequal value.  Cost model: every
+// workgroup costs its MFMA work (tile area) plus a fixed per-k-tile overhead that weighs more on small tiles;
+// the grid costs max-per-CU work.  tile: 0 = model, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128.
 template <int OP>
-int dispatch_tile(const P& p, int nz, hipStream_t st) {
-  const long big = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * nz;
-  // 128x128 tiles when they fill the 256 CUs at least ~1.5x, else 64x64 to get more workgroups
-  if (big >= 384 || (p.M > 64 && p.N > 64 && big >= 192)) return launch<OP, 128, 128>(p, nz, st);
-  return launch<OP, 64, 64>(p, nz, st);
+int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
+  if (tile == 0) {
+    static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
+    static const double eff[4] = {1.00, 0.80, 0.90, 0.90};   // relative MFMA efficiency of the tile shape
+    double best = 1e300;
+    for (int t = 0; t < 4; ++t) {
+      const long blocks = (long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * nz;
+      const long per_cu = (blocks + 255) / 256;               // workgroups the busiest CU executes
+      const double cost = (double)per_cu * bm[t] * bn[t] / eff[t];
+      if (cost < best * 0.999) { best = cost; tile = t + 1; }
+    }
+  }
+  switch (tile) {
+    case 2: return launch<OP, 64, 64>(p, nz, st);
+    case 3: return launch<OP, 128, 64>(p, nz, st);
+    case 4: return launch<OP, 64, 128>(p, nz, st);
+    default: return launch<OP, 128, 128>(p, nz, st);
+  }
 }
 
 }  // namespace
@@ -367,35 +433,35 @@ extern "C" int ick_gemm_f32(const IckGemm* d, void* stream) {
     case ICK_OP_NT:
       ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "NT: lda, ldb must be multiples of 4 (rows readable up to roundup4(K))");
       ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "NT: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_NT>(p, nz, st);
+      return dispatch_tile<ICK_OP_NT>(p, nz, st, d->tile);
     case ICK_OP_NN:
       ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "NN: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
       ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "NN: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_NN>(p, nz, st);
+      return dispatch_tile<ICK_OP_NN>(p, nz, st, d->tile);
     case ICK_OP_TN:
       ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "TN: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
       ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "TN: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_TN>(p, nz, st);
+      return dispatch_tile<ICK_OP_TN>(p, nz, st, d->tile);
     case ICK_OP_CONV_FWD:
       ICK_REQUIRE(p.Cin % BK == 0, "CONV_FWD: Cin=%d must be a multiple of %d", p.Cin, BK);
       ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * p.Cin && p.ldb == p.K,
                   "CONV_FWD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_FWD>(p, nz, st);
+      return dispatch_tile<ICK_OP_CONV_FWD>(p, nz, st, d->tile);
     case ICK_OP_CONV_FWD_C4:
       ICK_REQUIRE(p.Cin == 4, "CONV_FWD_C4: Cin must be 4");
       ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * 4 && p.ldb == p.K,
                   "CONV_FWD_C4: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_FWD_C4>(p, nz, st);
+      return dispatch_tile<ICK_OP_CONV_FWD_C4>(p, nz, st, d->tile);
     case ICK_OP_CONV_DGRAD:
       ICK_REQUIRE(p.Cout % BK == 0 && p.Cin % 4 == 0, "CONV_DGRAD: Cout %% 16 and Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Nb * p.H * p.W && p.N == p.Cin && p.K == p.R * p.S * p.Cout,
                   "CONV_DGRAD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_DGRAD>(p, nz, st);
+      return dispatch_tile<ICK_OP_CONV_DGRAD>(p, nz, st, d->tile);
     case ICK_OP_CONV_WGRAD:
       ICK_REQUIRE(p.Cout % 4 == 0 && p.Cin % 4 == 0, "CONV_WGRAD: Cout %% 4 and Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Cout && p.N == p.R * p.S * p.Cin && p.K == p.Nb * p.Ho * p.Wo && p.lda == p.Cout,
                   "CONV_WGRAD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_WGRAD>(p, nz, st);
+      return dispatch_tile<ICK_OP_CONV_WGRAD>(p, nz, st, d->tile);
     default:
       return ick::fail(-1, "ick_gemm_f32: unknown op %d", d->op);
   }

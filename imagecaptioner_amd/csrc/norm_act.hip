@@ -125,6 +125,47 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
   }
 }
 
+__global__ void bn_train_apply_kernel(const float* __restrict__ x, const double* __restrict__ sum,
+                                      const double* __restrict__ sq, float count, const float* __restrict__ gamma,
+                                      const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                      float momentum, float eps, const float* __restrict__ res, float* __restrict__ y,
+                                      float* __restrict__ smean, float* __restrict__ sinv, long total4, int C4, int relu) {
+  const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int c4 = (int)(i0 % C4);
+  float sc[4], sh[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c4 * 4 + k;
+    const double meand = sum[c] / (double)count;
+    double vard = sq[c] / (double)count - meand * meand;
+    vard = vard > 0.0 ? vard : 0.0;
+    const float inv = (float)(1.0 / sqrt(vard + (double)eps));
+    const float g = gamma[c];
+    sc[k] = g * inv;
+    sh[k] = beta[c] - (float)meand * g * inv;
+    if (i0 < C4) {            // exactly one thread per channel group publishes the statistics
+      smean[c] = (float)meand;
+      sinv[c] = inv;
+      if (rmean) {
+        const float var = (float)vard;
+        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)meand;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+      }
+    }
+  }
+  for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    float4 o = make_float4(fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3]));
+    if (res) {
+      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+}
+
 // BN backward pass 1: per channel sum(g) and sum(g * xhat), g = dy * (y > 0) when y != NULL.
 // Block = 256 threads as (ROWS x C4 lanes); each thread owns 4 channels, strides over rows; LDS combine, atomics out.
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
@@ -178,7 +219,10 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ inv, const float* __restrict__ gamma,
                                     const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float invM,
                                     float* __restrict__ dx, float* __restrict__ gout, long total4, int C4,
-                                    int use_batch_stats) {
+                                    int use_batch_stats, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // the parameter gradients are the two reductions themselves: dgamma += sum(g*xhat), dbeta += sum(g)
+  if (dgamma && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < 4 * C4; c += blockDim.x) { dgamma[c] += sum_gx[c]; dbeta[c] += sum_g[c]; }
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4);
     float4 g = reinterpret_cast<const float4*>(dy)[i];
@@ -503,12 +547,31 @@ int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const flo
 
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const float* sum_g, const float* sum_gx, float* dx, float* g_out, long M, int C,
-                     int use_batch_stats, void* stream) {
+                     int use_batch_stats, float* dgamma, float* dbeta, void* stream) {
   ICK_REQUIRE(dy && x && mean && invstd && gamma && dx && C % 4 == 0 && M > 0, "ick_bn_bwd_apply: bad arguments");
+  ICK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "ick_bn_bwd_apply: dgamma and dbeta go together");
   const long total4 = M * (C / 4);
   ICK_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, sum_g,
-                     sum_gx, 1.0f / (float)M, dx, g_out, total4, C / 4, use_batch_stats);
+                     sum_gx, 1.0f / (float)M, dx, g_out, total4, C / 4, use_batch_stats, dgamma, dbeta);
   return ick::launch_status("bn_bwd_apply");
+}
+
+// train-mode BatchNorm forward in ONE pass over the raw conv output: every thread derives scale/shift of its own
+// 4 channels from the fp64 batch sums the conv epilogue produced (the grid stride is a multiple of C/4, so a
+// thread's channels never change), block 0 also stores mean / invstd for backward and updates the running stats.
+int ick_bn_train_apply(const float* x, const double* sum, const double* sq, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, const float* residual,
+                       float* y, float* save_mean, float* save_invstd, long M, int C, int relu, void* stream) {
+  ICK_REQUIRE(x && sum && sq && gamma && beta && y && save_mean && save_invstd && M > 0 && C % 4 == 0 && (C / 4) <= 1024 &&
+              ((C / 4) & (C / 4 - 1)) == 0, "ick_bn_train_apply: C/4 must be a power of two <= 1024");
+  const int C4 = C / 4;
+  const long total4 = M * C4;
+  int grid = grid_for(total4);
+  const int q = C4 > NT ? C4 / NT : 1;          // grid * NT must be a multiple of C4
+  grid = (grid + q - 1) / q * q;
+  ICK_LAUNCH(bn_train_apply_kernel, dim3(grid), dim3(NT), 0, ST, x, sum, sq, (float)M, gamma, beta, running_mean,
+             running_var, momentum, eps, residual, y, save_mean, save_invstd, total4, C4, relu);
+  return ick::launch_status("bn_train_apply");
 }
 
 int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {

@@ -233,20 +233,36 @@ class BatchNorm2d(nn.Module):
         self.eps, self.momentum = eps, momentum
 
 
-def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool, w_packed=None):
-    """raw = conv(x); y = [relu](bn(raw) [+ residual]).  Train mode: batch statistics from the conv epilogue,
-    running stats updated (also for frozen layers).  Returns (y, raw, mean, invstd)."""
+class _Arena:
+    """One zero-filled buffer handed out in slices: a single fill kernel instead of one per BatchNorm."""
+
+    def __init__(self, n: int, dtype, device):
+        self.buf = torch.zeros(max(n, 1), dtype=dtype, device=device)
+        self.off = 0
+
+    def take(self, rows: int, cols: int) -> torch.Tensor:
+        n = rows * cols
+        v = self.buf[self.off:self.off + n].view(rows, cols)
+        self.off += n
+        return v
+
+
+def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool, w_packed=None, arena=None, counters=None):
+    """raw = conv(x); y = [relu](bn(raw) [+ residual]).  Train mode: batch statistics from the conv epilogue (fp64
+    sums), normalisation + running-stat update in one pass over raw (also for frozen layers).
+    Returns (y, raw, mean, invstd)."""
     w = w_packed if w_packed is not None else conv.packed()
     if train:
         C = w.shape[0]
-        stats = torch.zeros(2, C, dtype=torch.float64, device=x.device)     # fp64 sum / sum-of-squares accumulators
+        stats = arena.take(2, C) if arena is not None else torch.zeros(2, C, dtype=torch.float64, device=x.device)
         raw = ops.conv_fwd(x, w, conv.stride, conv.padding, stats=(stats[0], stats[1]))
-        count = raw.numel() // C
-        co = ops.bn_finalize(stats[0], stats[1], count, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                             bn.momentum, bn.eps)
-        bn.num_batches_tracked += 1          # bookkeeping counter (int64), not part of the arithmetic
-        y = ops.scale_shift_act(raw, co[0], co[1], residual, relu)
-        return y, raw, co[2], co[3]
+        y, mean, inv = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
+                                          bn.eps, residual, relu)
+        if counters is not None:
+            counters.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked += 1      # bookkeeping counter (int64), not part of the arithmetic
+        return y, raw, mean, inv
     co = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
     raw = ops.conv_fwd(x, w, conv.stride, conv.padding)
     y = ops.scale_shift_act(raw, co[0], co[1], residual, relu)
@@ -303,25 +319,33 @@ class ResNetTrunkFn(Function):
         if any(p.requires_grad for p in list(stem.parameters()) + list(resnet[1].parameters())):
             raise NotImplementedError("the 7x7 stem is frozen in the reference (student_model.py:23-27); its backward is not built")
         w4 = ops.nchw3_to_nhwc4(_c(stem.weight.detach()))          # (64,3,7,7) -> (64,7,7,4), zero 4th channel
-        y, _, _, _ = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4)
-        y = ops.maxpool3x3s2(y)
         blocks: List[Bottleneck] = [b for li in (4, 5, 6, 7) for b in resnet[li]]
+        arena = counters = None
+        if train:
+            nch = 64 + sum(b.bn1.weight.numel() + b.bn2.weight.numel() + b.bn3.weight.numel() +
+                           (b.downsample[1].weight.numel() if b.downsample is not None else 0) for b in blocks)
+            arena, counters = _Arena(2 * nch, torch.float64, images.device), []
+        cb = lambda x, c, b, relu, res: conv_bn(x, c, b, relu, res, train, arena=arena, counters=counters)
+        y, _, _, _ = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters)
+        y = ops.maxpool3x3s2(y)
         first = next((i for i, b in enumerate(blocks) if _block_trainable(b)), len(blocks))
         want_bwd = any(ctx.needs_input_grad) and first < len(blocks)   # (forward itself always runs in no-grad mode)
         recs = []
         for i, blk in enumerate(blocks):
             keep = want_bwd and i >= first
-            a1, r1, m1, i1 = conv_bn(y, blk.conv1, blk.bn1, True, None, train)
-            a2, r2, m2, i2 = conv_bn(a1, blk.conv2, blk.bn2, True, None, train)
+            a1, r1, m1, i1 = cb(y, blk.conv1, blk.bn1, True, None)
+            a2, r2, m2, i2 = cb(a1, blk.conv2, blk.bn2, True, None)
             if blk.downsample is not None:
-                idt, rd, md, idv = conv_bn(y, blk.downsample[0], blk.downsample[1], False, None, train)
+                idt, rd, md, idv = cb(y, blk.downsample[0], blk.downsample[1], False, None)
             else:
                 idt, rd, md, idv = y, None, None, None
-            out, r3, m3, i3 = conv_bn(a2, blk.conv3, blk.bn3, True, idt, train)
+            out, r3, m3, i3 = cb(a2, blk.conv3, blk.bn3, True, idt)
             if keep:
                 recs.append(dict(x=y, a1=a1, r1=r1, m1=m1, i1=i1, a2=a2, r2=r2, m2=m2, i2=i2, out=out, r3=r3, m3=m3,
                                  i3=i3, rd=rd, md=md, idv=idv))
             y = out
+        if counters:
+            torch._foreach_add_(counters, 1)       # all num_batches_tracked counters in one launch (bookkeeping)
         ctx.blocks, ctx.first, ctx.recs, ctx.train = blocks, first, recs, train
         Nb, H, W, C = y.shape
         return y.view(Nb, H * W, C)                                  # (B,49,2048): NHWC is already "permute(0,2,1)"
@@ -332,6 +356,9 @@ class ResNetTrunkFn(Function):
         if not recs:
             return (None,) * (3 + sum(1 for b in blocks for _ in b.parameters()) + 3)
         d = _c(dy).view(recs[-1]["out"].shape)
+        nch = sum(b.bn1.weight.numel() + b.bn2.weight.numel() + b.bn3.weight.numel() +
+                  (b.downsample[1].weight.numel() if b.downsample is not None else 0) for b in blocks[first:])
+        sums_arena = _Arena(2 * nch, torch.float32, d.device)
         for i in range(len(blocks) - 1, first - 1, -1):
             blk, r = blocks[i], recs[i - first]
             need_in = i > first
@@ -339,7 +366,8 @@ class ResNetTrunkFn(Function):
             def bnb(dyv, ymask, raw, mean, inv, bn, want_g=False):
                 if train:
                     return ops.bn_bwd(dyv, ymask, raw, mean, inv, bn.weight, grad_buf(bn.weight) if bn.weight.requires_grad else None,
-                                      grad_buf(bn.bias) if bn.weight.requires_grad else None, want_g, True)
+                                      grad_buf(bn.bias) if bn.weight.requires_grad else None, want_g, True,
+                                      sums=sums_arena.take(2, bn.weight.numel()))
                 raise NotImplementedError("backward through eval-mode BatchNorm is not needed by the KD step")
 
             def wgrad(conv, dyv, xin):

@@ -42,12 +42,30 @@ def zeros(*shape, device=None) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- raw GEMM
+_FORCE_TILE = [0]       # tools/profile_step_gemms.py sweeps tile shapes through this
+
+
+def _load_tuned():
+    """Measured best tile per (op, M, N, K, batch, splitk) for the KD step's shapes (tools/profile_step_gemms.py on an
+    MI355X); shapes not in the table use the library's wave-quantisation model."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles.json")
+    try:
+        return {k: int(v) for k, v in json.load(open(path)).items()}
+    except FileNotFoundError:
+        return {}
+
+
+_TUNED = _load_tuned()
+
+
 def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *,
              bias: Optional[int] = None, residual: Optional[int] = None, ldr: int = 0, act: int = ACT_NONE,
              alpha: float = 1.0, batch: Tuple[int, int] = (1, 1),
              strides: Tuple[int, int, int, int, int, int] = (0, 0, 0, 0, 0, 0), splitk: int = 1,
              accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
-             conv: Optional[Tuple[int, ...]] = None) -> None:
+             conv: Optional[Tuple[int, ...]] = None, tile: int = 0) -> None:
     d = IckGemm()
     d.A, d.B, d.C = A, B, C
     d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
@@ -59,6 +77,7 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
     d.splitk, d.accumulate, d.alpha = splitk, int(accumulate), alpha
     if conv is not None:
         d.Nb, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.R, d.S, d.stride, d.pad = conv
+    d.tile = tile or _FORCE_TILE[0] or _TUNED.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
     check(_lib.lib().ick_gemm_f32(ctypes.byref(d), _st()), "ick_gemm_f32")
 
 
@@ -290,23 +309,35 @@ def scale_shift_act(x, scale, shift, residual, relu: bool, out=None):
     return y
 
 
-def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batch_stats: bool = True):
+def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batch_stats: bool = True, sums=None):
     """Backward through [relu](bn(x)[+res]).  dy: grad wrt the block output; y_mask: that output (relu mask) or None.
-    Accumulates dgamma/dbeta (+=); returns (dx, g) with g = masked dy (gradient of the residual branch) if want_g."""
+    Accumulates dgamma/dbeta (+=) inside the apply kernel; returns (dx, g) with g = masked dy (gradient of the
+    residual branch) if want_g.  `sums`: a zeroed (2,C) slice of a caller-owned arena (saves one fill per BN)."""
     C = x.shape[-1]
     M = x.numel() // C
-    sums = zeros(2, C, device=x.device)
+    if sums is None:
+        sums = zeros(2, C, device=x.device)
     check(_lib.lib().ick_bn_bwd_reduce(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                        sums[0].data_ptr(), sums[1].data_ptr(), M, C, _st()), "ick_bn_bwd_reduce")
     dx = torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
     check(_lib.lib().ick_bn_bwd_apply(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                       gamma.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), dx.data_ptr(), _ptr(g),
-                                      M, C, int(batch_stats), _st()), "ick_bn_bwd_apply")
-    if dgamma is not None:
-        add(dgamma, sums[1], out=dgamma)   # dgamma += sum(g*xhat)
-        add(dbeta, sums[0], out=dbeta)     # dbeta  += sum(g)
+                                      M, C, int(batch_stats), _ptr(dgamma), _ptr(dbeta), _st()), "ick_bn_bwd_apply")
     return dx, g
+
+
+def bn_train_apply(raw, stats, gamma, beta, rmean, rvar, momentum, eps, residual, relu: bool):
+    """y = [relu](batchnorm_train(raw) [+ residual]) from the fp64 sums of the conv epilogue, one pass; returns
+    (y, save_mean, save_invstd) and updates the running statistics."""
+    C = raw.shape[-1]
+    y = torch.empty_like(raw)
+    sv = empty(2, C, device=raw.device)
+    check(_lib.lib().ick_bn_train_apply(raw.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(),
+                                        beta.data_ptr(), _ptr(rmean), _ptr(rvar), momentum, eps, _ptr(residual), y.data_ptr(),
+                                        sv[0].data_ptr(), sv[1].data_ptr(), raw.numel() // C, C, int(relu), _st()),
+          "ick_bn_train_apply")
+    return y, sv[0], sv[1]
 
 
 def maxpool3x3s2(x):
@@ -415,14 +446,15 @@ def _skinny_splitk(M: int, N: int, K: int) -> int:
 
 
 def gemm_nt(x: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Tensor, *, bias=None, residual=None,
-            accumulate=False, act=ACT_NONE, splitk: int = 0):
+            accumulate=False, act=ACT_NONE, splitk: int = 0, zeroed: bool = False):
     """out (M,N) = act(x (M,K) @ W^T + bias) [+ residual]; W given by raw pointer + row pitch (column slices of a
-    wider weight, e.g. the W_h / W_f halves of the decoder's attention matrix)."""
+    wider weight, e.g. the W_h / W_f halves of the decoder's attention matrix).  zeroed=True: the caller guarantees
+    `out` is already zero (slice of a zero-filled arena), so a split-K launch needs no fill kernel of its own."""
     M = x.numel() // K
     if splitk <= 0:
         splitk = _skinny_splitk(M, N, K) if act == ACT_NONE else 1
     if splitk > 1:
-        if not accumulate:
+        if not accumulate and not zeroed:
             out.zero_()
         gemm_raw(OP_NT, x.data_ptr(), w_ptr, out.data_ptr(), M, N, K, K, ldb, N, bias=_ptr(bias), residual=_ptr(residual),
                  ldr=N, splitk=splitk)
@@ -433,13 +465,13 @@ def gemm_nt(x: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Te
 
 
 def gemm_nn(dy: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Tensor, *, residual=None,
-            accumulate=False, splitk: int = 0):
+            accumulate=False, splitk: int = 0, zeroed: bool = False):
     """out (M,K) = dy (M,N) @ W (N,K) [+ residual]; W by raw pointer with row pitch ldb."""
     M = dy.numel() // N
     if splitk <= 0:
         splitk = _skinny_splitk(M, K, N)
     if splitk > 1:
-        if not accumulate:
+        if not accumulate and not zeroed:
             out.zero_()
         gemm_raw(OP_NN, dy.data_ptr(), w_ptr, out.data_ptr(), M, K, N, N, ldb, K, residual=_ptr(residual), ldr=K, splitk=splitk)
     else:

@@ -160,22 +160,25 @@ class DecoderFn(Function):
         Call = ops.empty(NL, T, B, H, device=dev)
         Gates = ops.empty(NL, T, B, 4 * H, device=dev) if keep else None
         Hd = ops.empty(NL - 1, T, B, H, device=dev) if p_lstm > 0 else None                   # dropped inter-layer inputs
-        hW = ops.empty(T, B, E, device=dev)
+        # zero-filled arenas: the GEMV-sized GEMMs of the loop are split-K (fp32 atomics) and need zeroed outputs;
+        # one fill per arena instead of one per launch
+        hW = ops.zeros(T, B, E, device=dev)
         attw = ops.empty(T, B, P, device=dev)
         ctxs = ops.empty(T, B, E, device=dev)
-        X = ops.empty(T, B, E, device=dev)
+        X = ops.zeros(T, B, E, device=dev)
         zero_h = ops.zeros(B, H, device=dev)
-        G = ops.empty(B, 4 * H, device=dev)
+        Gall = ops.zeros(T, NL, B, 4 * H, device=dev)
         seeds = [[hnn._next_seed() for _ in range(T)] for _ in range(NL - 1)] if p_lstm > 0 else None
         for t in range(T):
             h_top = Hall[NL - 1, t - 1] if t > 0 else zero_h
-            ops.gemm_nt(h_top, Wa.data_ptr(), E, H, H + E, hW[t])
+            ops.gemm_nt(h_top, Wa.data_ptr(), E, H, H + E, hW[t], zeroed=True)
             ops.attn_step_fwd(Uf, hW[t], feats, attw[t], ctxs[t])
-            ops.gemm_nt(ctxs[t], Wc.data_ptr() + E * fs, E, E, 2 * E, X[t], residual=Xe[t])
+            ops.gemm_nt(ctxs[t], Wc.data_ptr() + E * fs, E, E, 2 * E, X[t], residual=Xe[t], zeroed=True)
             inp = X[t]
             for l in range(NL):
                 wi, wh, bi, bh = dec.lstm.layer(l)
-                ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G)
+                G = Gall[t, l]
+                ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G, zeroed=True)
                 if t > 0:
                     ops.gemm_nt(Hall[l, t - 1], wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
                 ops.lstm_cell_fwd(G, bi, bh, Call[l, t - 1] if t > 0 else None, Gates[l, t] if keep else None, Call[l, t],
@@ -235,34 +238,32 @@ class DecoderFn(Function):
             dHs = ops.zeros(T, B, H, device=dev)
         # ---- BPTT
         DG = ops.empty(NL, T, B, 4 * H, device=dev)
-        dX = ops.empty(T, B, E, device=dev)
+        dX = ops.zeros(T, B, E, device=dev)                 # zero-filled arenas for the split-K GEMV-sized products
         dhW = ops.empty(T, B, E, device=dev)
         dUf = ops.zeros(B, P, E, device=dev)
         dfeats = ops.zeros(B, P, E, device=dev)
-        carry = [ops.zeros(B, H, device=dev) for _ in range(NL)]
-        carry_next = [ops.empty(B, H, device=dev) for _ in range(NL)]
+        carry = ops.zeros(T, NL, B, H, device=dev)          # carry[t, l]: dL/dh_l flowing INTO step t from step t+1
         carry_c = [ops.zeros(B, H, device=dev) for _ in range(NL)]
-        d_inp = ops.empty(B, H, device=dev)
-        dctx = ops.empty(B, E, device=dev)
+        d_inp = ops.zeros(T, NL, B, H, device=dev)
+        dctx = ops.zeros(T, B, E, device=dev)
         for t in range(T - 1, -1, -1):
             for l in range(NL - 1, -1, -1):
                 wi, wh, _, _ = dec.lstm.layer(l)
-                dh_a = dHs[t] if l == NL - 1 else d_inp
-                ops.lstm_cell_bwd(dh_a, carry[l] if t < T - 1 else None, carry_c[l] if t < T - 1 else None, Gates[l, t],
+                dh_a = dHs[t] if l == NL - 1 else d_inp[t, l + 1]
+                ops.lstm_cell_bwd(dh_a, carry[t, l] if t < T - 1 else None, carry_c[l] if t < T - 1 else None, Gates[l, t],
                                   Call[l, t], Call[l, t - 1] if t > 0 else None, DG[l, t], carry_c[l])
                 if t > 0:
-                    ops.gemm_nn(DG[l, t], wh.data_ptr(), 4 * H, H, H, carry_next[l])
+                    ops.gemm_nn(DG[l, t], wh.data_ptr(), 4 * H, H, H, carry[t - 1, l], zeroed=True)
                 if l > 0:
-                    ops.gemm_nn(DG[l, t], wi.data_ptr(), 4 * H, H, H, d_inp)
+                    ops.gemm_nn(DG[l, t], wi.data_ptr(), 4 * H, H, H, d_inp[t, l], zeroed=True)
                     if s["p_lstm"] > 0:
-                        ops.dropout(d_inp, d_inp, s["p_lstm"], s["seeds"][l - 1][t])
+                        ops.dropout(d_inp[t, l], d_inp[t, l], s["p_lstm"], s["seeds"][l - 1][t])
                 else:
-                    ops.gemm_nn(DG[0, t], wi.data_ptr(), 4 * H, E, E, dX[t])
-            ops.gemm_nn(dX[t], Wc.data_ptr() + E * fs, E, E, 2 * E, dctx)
-            ops.attn_step_bwd(dctx, s["attw"][t], s["Uf"], s["hW"][t], s["feats"], dUf, dfeats, dhW[t])
+                    ops.gemm_nn(DG[0, t], wi.data_ptr(), 4 * H, E, E, dX[t], zeroed=True)
+            ops.gemm_nn(dX[t], Wc.data_ptr() + E * fs, E, E, 2 * E, dctx[t], zeroed=True)
+            ops.attn_step_bwd(dctx[t], s["attw"][t], s["Uf"], s["hW"][t], s["feats"], dUf, dfeats, dhW[t])
             if t > 0:
-                ops.gemm_nn(dhW[t], Wa.data_ptr(), E, H, H + E, carry_next[NL - 1], accumulate=True)
-            carry, carry_next = carry_next, carry
+                ops.gemm_nn(dhW[t], Wa.data_ptr(), E, H, H + E, carry[t - 1, NL - 1], accumulate=True)
         # ---- deferred weight gradients, batched over all steps
         for l in range(NL):
             wi, wh, bi, bh = dec.lstm.layer(l)

@@ -67,6 +67,7 @@ typedef struct IckGemm {
   float alpha;
   /* convolution geometry (ICK_OP_CONV_*): X [Nb][H][W][Cin], Y [Nb][Ho][Wo][Cout] */
   int32_t Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+  int32_t tile;                                 /* 0 = choose by the wave-quantisation model; 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 */
 } IckGemm;
 
 int ick_gemm_f32(const IckGemm* desc, void* stream);
@@ -91,7 +92,10 @@ int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const flo
                       float* sum_g, float* sum_gx, int64_t M, int C, void* stream);          /* += sum(g), sum(g*xhat); g = dy*(y>0) if y */
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const float* sum_g, const float* sum_gx, float* dx, float* g_out,
-                     int64_t M, int C, int use_batch_stats, void* stream);
+                     int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, void* stream); /* dgamma/dbeta (optional) += the two sums */
+int ick_bn_train_apply(const float* x, const double* sum, const double* sq, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, const float* residual,
+                       float* y, float* save_mean, float* save_invstd, int64_t M, int C, int relu, void* stream); /* bn_finalize + scale_shift_act in one pass */
 int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream); /* nn.MaxPool2d(3,2,1), NHWC */
 
 /* ------------------------------------------------------------------ LayerNorm / softmax / small utilities

@@ -1,0 +1,94 @@
+#!/usr/bin/env python3
+"""Per-shape timing of every igemm_f32 launch of one KD train step (GPU box).
+Records the descriptors of one eager step at B=64, then replays each distinct descriptor in isolation
+(L2-warm, 20 iterations) and prints time, count, TFLOP/s, sorted by total time in the step."""
+import collections
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imagecaptioner_amd import _lib, ops  # noqa: E402
+from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models  # noqa: E402
+from imagecaptioner_amd.utils.seeded_init import synthetic_batch  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+OPN = ["NT", "NN", "TN", "CONV_FWD", "CONV_FWD_C4", "CONV_DGRAD", "CONV_WGRAD"]
+records = []
+orig = ops.gemm_raw
+
+
+def rec(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw):
+    records.append((op, M, N, K, lda, ldb, ldc, kw.get("batch", (1, 1)), kw.get("strides", (0,) * 6), kw.get("splitk", 1),
+                    kw.get("conv"), kw.get("act", 0), kw.get("bias") is not None, kw.get("residual") is not None,
+                    kw.get("stat_sum") is not None, kw.get("accumulate", False), kw.get("ldr", 0)))
+    return orig(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw)
+
+
+student, teacher, projectors = build_kd_models(device="cuda")
+tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=B, use_graph=False)
+images, caps = synthetic_batch(B, 5000, 16)
+tr.train_step(images.cuda(), caps.cuda())
+ops.gemm_raw = rec
+tr.train_step()
+ops.gemm_raw = orig
+torch.cuda.synchronize()
+print(f"{len(records)} igemm launches per step at B={B}")
+cnt = collections.Counter(records)
+big = torch.empty(1 << 28, device="cuda").normal_()         # 1 GiB scratch for operands
+out = torch.empty(1 << 27, device="cuda")
+stat = torch.zeros(2, 4096, dtype=torch.float64, device="cuda")
+rows = []
+TN_ = ["model", "128x128", "64x64", "128x64", "64x128"]
+
+
+def timeit(f, iters=10):
+    f(); f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+for r, n in cnt.items():
+    op, M, N, K, lda, ldb, ldc, batch, strides, splitk, conv, act, bias, res, st, acc, ldr = r
+    kw = dict(batch=batch, strides=strides, splitk=splitk, conv=conv, act=act, accumulate=acc, ldr=ldr)
+    if bias:
+        kw["bias"] = big.data_ptr()
+    if res:
+        kw["residual"] = big.data_ptr() + (1 << 29)
+    if st:
+        kw["stat_sum"], kw["stat_sq"] = stat[0].data_ptr(), stat[1].data_ptr()
+    a, b = big.data_ptr(), big.data_ptr() + (1 << 29)
+    ts = []
+    for tile in range(5):
+        ts.append(timeit(lambda: orig(op, a, b, out.data_ptr(), M, N, K, lda, ldb, ldc, tile=tile, **kw)))
+    nb = batch[0] * batch[1]
+    fl = 2.0 * M * N * K * nb * (0.75 if op == 4 else 1.0)
+    best = min(range(1, 5), key=lambda i: ts[i])
+    rows.append((ts[0] * n, n, ts[0], fl / ts[0] / 1e12, OPN[op], M, N, K, nb, splitk, conv, ts, best))
+rows.sort(reverse=True, key=lambda r: r[0])
+tot = sum(r[0] for r in rows)
+totb = sum(r[11][r[12]] * r[1] for r in rows)
+print(f"sum of isolated igemm time per step: model {tot * 1e3:.2f} ms; best tile per shape {totb * 1e3:.2f} ms")
+print(f"{'total us':>9s} {'n':>4s} {'model us':>8s} {'TF/s':>6s}  {'128x128':>8s} {'64x64':>8s} {'128x64':>8s} {'64x128':>8s} best     op          M      N      K  batch splitk conv")
+for tt, n, t, tf, opn, M, N, K, nb, sk, conv, ts, best in rows[:90]:
+    print(f"{tt * 1e6:9.0f} {n:4d} {t * 1e6:8.1f} {tf:6.1f}  " + " ".join(f"{x * 1e6:8.1f}" for x in ts[1:]) +
+          f" {TN_[best]:8s} {opn:11s} {M:6d} {N:6d} {K:6d} {nb:5d} {sk:5d}  {conv if conv else ''}")
+
+# ---- autotune table: best tile per descriptor where it beats the model's choice by > 3 %
+import json
+table = {}
+for tt, n, t, tf, opn, M, N, K, nb, sk, conv, ts, best in rows:
+    if ts[best] < 0.97 * ts[0]:
+        table[f"{OPN.index(opn)}:{M}:{N}:{K}:{nb}:{sk}"] = best
+out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"tuned_tiles_B{B}.json")
+os.makedirs(os.path.dirname(out_path), exist_ok=True)
+json.dump(table, open(out_path, "w"), indent=0, sort_keys=True)
+print(f"wrote {len(table)} tuned entries to {out_path}")
