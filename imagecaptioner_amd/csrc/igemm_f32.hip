@@ -46,6 +46,7 @@ struct P {  // kernel parameters (by value)
 
 // which fetch pattern each op uses for its A and B operands
 __host__ __device__ constexpr bool a_kcontig(int op) { return op != ICK_OP_TN && op != ICK_OP_CONV_WGRAD; }
+__host__ __device__ constexpr bool is_dgrad(int op) { return op == ICK_OP_CONV_DGRAD || op == ICK_OP_CONV_DGRAD_S2; }
 __host__ __device__ constexpr bool b_kcontig(int op) {
   return op == ICK_OP_NT || op == ICK_OP_CONV_FWD || op == ICK_OP_CONV_FWD_C4;
 }
@@ -98,12 +99,22 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
   // batch / split-K decomposition of blockIdx.z
   int z = blockIdx.z, split = 0;
   if (p.splitk > 1) { split = z; z = 0; }
+  // stride-2 dgrad: blockIdx.z = parity class (py,px) of the input pixel; only the taps r = r0, r0+2, .. with
+  // (iy + pad - r) even can reach it, so each class is a dense GEMM over its own nr*ns taps (no multiplies by zero)
+  int py = 0, px = 0, r0 = 0, s0 = 0, ns = 1, kcls = 0;
+  if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
+    py = z >> 1; px = z & 1; z = 0;
+    r0 = (py + p.pad) & 1; s0 = (px + p.pad) & 1;
+    const int nr = p.R > r0 ? (p.R - r0 + 1) / 2 : 0;
+    ns = p.S > s0 ? (p.S - s0 + 1) / 2 : 0;
+    kcls = nr * ns * p.Cout;
+  }
   const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
   const float* __restrict__ Ag = p.A + zo * p.sAo + zi * p.sAi;
   const float* __restrict__ Bg = p.B + zo * p.sBo + zi * p.sBi;
   const long coff = zo * p.sCo + zi * p.sCi;
   const int kbeg = split * p.kps;
-  const int kend = min(p.K, kbeg + p.kps);
+  const int kend = OP == ICK_OP_CONV_DGRAD_S2 ? kcls : min(p.K, kbeg + p.kps);
   const int nkt = (kend - kbeg + BK - 1) / BK;
 
   // ---------------------------------------------------------------- per-thread fetch state
@@ -122,6 +133,11 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
         const int oy = r / p.Wo, ox = r - oy * p.Wo;
         a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad;
         a_ptr[i] = Ag + (long)b * p.H * p.W * p.Cin;
+      } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {  // rows = input pixels of this parity class
+        const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int r = m - b * hw;
+        const int iy = 2 * (r / w2) + py, ix = 2 * (r % w2) + px;
+        a_y[i] = iy + p.pad; a_x[i] = ix + p.pad;
+        a_ptr[i] = Ag + (long)b * p.Ho * p.Wo * p.Cout;
       } else {  // CONV_DGRAD: rows are input pixels, gather from dY
         const int hw = p.H * p.W; const int b = m / hw; const int r = m - b * hw;
         const int iy = r / p.W, ix = r - iy * p.W;
@@ -202,6 +218,17 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
         amask |= ok ? (1u << i) : 0u;
         ra[i] = ldg4u(a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co, ok, Ag);
       }
+    } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
+      const int q = k0 / p.Cout; const int co = k0 - q * p.Cout + a_k4;
+      const int r = r0 + 2 * (q / ns), s = s0 + 2 * (q % ns);
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int ty = a_y[i] - r, tx = a_x[i] - s;        // even by construction
+        const int oy = ty >> 1, ox = tx >> 1;
+        const bool ok = a_ok[i] && ty >= 0 && tx >= 0 && oy < p.Ho && ox < p.Wo && (k0 + a_k4 < kend);
+        amask |= ok ? (1u << i) : 0u;
+        ra[i] = ldg4u(a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co, ok, Ag);
+      }
     } else {  // A [K][M]
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
@@ -221,6 +248,16 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
       }
     } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
       const int tap = k0 / p.Cout; const int co0 = k0 - tap * p.Cout;
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        const int co = co0 + b_y[i];
+        const bool ok = b_ok[i] && (k0 + b_y[i] < kend);
+        bmask |= ok ? (1u << i) : 0u;
+        rb[i] = ldg4u(b_ptr[i] + ((long)co * p.R * p.S + tap) * p.Cin, ok, Bg);
+      }
+    } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
+      const int q = k0 / p.Cout; const int co0 = k0 - q * p.Cout;
+      const int tap = (r0 + 2 * (q / ns)) * p.S + s0 + 2 * (q % ns);
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
         const int co = co0 + b_y[i];
@@ -343,8 +380,13 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq += v * v;
             v = act_fn(v + bias, act);
-            const long o = (long)m * p.ldc + n;
-            if (Rg) v += Rg[(long)m * p.ldr + n];
+            long mr = m;
+            if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // class row -> pixel row of the full-resolution dX
+              const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
+              mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
+            }
+            const long o = mr * p.ldc + n;
+            if (Rg) v += Rg[mr * p.ldr + n];
             if (mode == 2) atomicAdd(Cg + o, v);
             else if (mode == 1) Cg[o] += v;
             else Cg[o] = v;
@@ -457,6 +499,12 @@ extern "C" int ick_gemm_f32(const IckGemm* d, void* stream) {
       ICK_REQUIRE(p.M == p.Nb * p.H * p.W && p.N == p.Cin && p.K == p.R * p.S * p.Cout,
                   "CONV_DGRAD: M/N/K do not match the geometry");
       return dispatch_tile<ICK_OP_CONV_DGRAD>(p, nz, st, d->tile);
+    case ICK_OP_CONV_DGRAD_S2:
+      ICK_REQUIRE(p.stride == 2 && p.H % 2 == 0 && p.W % 2 == 0, "CONV_DGRAD_S2: stride 2 and even H, W required");
+      ICK_REQUIRE(p.Cout % BK == 0 && p.Cin % 4 == 0, "CONV_DGRAD_S2: Cout %% 16 and Cin %% 4 required");
+      ICK_REQUIRE(p.M == p.Nb * (p.H / 2) * (p.W / 2) && p.N == p.Cin && p.K == p.R * p.S * p.Cout && nz == 1 &&
+                  p.splitk == 1, "CONV_DGRAD_S2: M must be the rows of ONE parity class; no batching / split-K");
+      return dispatch_tile<ICK_OP_CONV_DGRAD_S2>(p, 4, st, d->tile);
     case ICK_OP_CONV_WGRAD:
       ICK_REQUIRE(p.Cout % 4 == 0 && p.Cin % 4 == 0, "CONV_WGRAD: Cout %% 4 and Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Cout && p.N == p.R * p.S * p.Cin && p.K == p.Nb * p.Ho * p.Wo && p.lda == p.Cout,

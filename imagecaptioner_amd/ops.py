@@ -11,7 +11,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH, OP_CONV_DGRAD, OP_CONV_FWD, OP_CONV_FWD_C4,
+from ._lib import (ACT_GELU, ACT_NONE, ACT_RELU, ACT_TANH, OP_CONV_DGRAD, OP_CONV_DGRAD_S2, OP_CONV_FWD, OP_CONV_FWD_C4,
                    OP_CONV_WGRAD, OP_NN, OP_NT, OP_TN, IckGemm, check)
 
 _F32 = torch.float32
@@ -258,6 +258,12 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride
     assert dy.is_contiguous() and w.is_contiguous()
     dx = out if out is not None else empty(Nb, H, W, Cin, device=dy.device)
     K = R * S * Cout
+    if stride == 2 and H % 2 == 0 and W % 2 == 0:
+        # 4 parity classes of input pixels, each a dense GEMM over the taps that can reach it (4x fewer MACs)
+        gemm_raw(OP_CONV_DGRAD_S2, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), Nb * (H // 2) * (W // 2), Cin, K, 0, 0, Cin,
+                 residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+        return dx
     gemm_raw(OP_CONV_DGRAD, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, 0, 0, Cin,
              residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
              conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))

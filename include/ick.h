@@ -47,7 +47,8 @@ enum {
   ICK_OP_CONV_FWD = 3,  /* A = im2col(X NHWC), B = W [Cout][R*S*Cin]                             */
   ICK_OP_CONV_FWD_C4 = 4,/* same, Cin == 4 (padded RGB stem), K = R*S*4                          */
   ICK_OP_CONV_DGRAD = 5,/* A = gather(dY NHWC), B = W as [k=(tap,co)][n=ci]  -> dX NHWC          */
-  ICK_OP_CONV_WGRAD = 6 /* A = dY as [K=B*Ho*Wo][M=Cout], B = gather(X) [K][N=(tap,ci)] -> dW    */
+  ICK_OP_CONV_WGRAD = 6,/* A = dY as [K=B*Ho*Wo][M=Cout], B = gather(X) [K][N=(tap,ci)] -> dW    */
+  ICK_OP_CONV_DGRAD_S2 = 7 /* stride-2 dgrad split into the 4 input-pixel parity classes (grid.z): M = Nb*(H/2)*(W/2) */
 };
 enum { ICK_ACT_NONE = 0, ICK_ACT_RELU = 1, ICK_ACT_GELU = 2, ICK_ACT_TANH = 3 };
 
