@@ -39,7 +39,7 @@ struct P {  // kernel parameters (by value)
   long lda, ldb, ldc, ldr;
   int batch_inner;
   long sAo, sAi, sBo, sBi, sCo, sCi;
-  int splitk, kps, accumulate, act;
+  int splitk, kps, accumulate, act, tiles_n;
   float alpha;
   int Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
 };
@@ -94,7 +94,13 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order: the dispatcher deals workgroup ids round-robin over the 8 XCDs (each with its own L2);
+  // remap so that every XCD walks a CONTIGUOUS range of tiles (row-major over N then M): the A row panel
+  // (activations, the large operand) is then fetched into one L2 instead of up to eight (bijective for any grid).
+  const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // batch / split-K decomposition of blockIdx.z
   int z = blockIdx.z, split = 0;
@@ -334,21 +340,34 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) fetch(kt + 1);
+    // fragment registers are double-buffered by hand: the ds_reads of k-pair kk+2 are issued BEFORE the MFMAs of
+    // k-pair kk, so their LDS latency hides behind 4 x 64 MFMA cycles even with a single wave on the SIMD
+    float av[2][TM], bv[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[0][i] = As[buf][fk][fa + i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[0][j] = Bs[buf][fk][fb + j * 32];
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
+      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
+      if (kk + 2 < BK) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[nxt][i] = As[buf][kk + 2 + fk][fa + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[nxt][j] = Bs[buf][kk + 2 + fk][fb + j * 32];
+      }
       // the LDS write of tile kt+1 (other buffer: nobody reads it during tile kt) goes in the shadow of the
       // second half of this tile's MFMAs instead of between the last MFMA and the barrier
       if (kk == STASH_AT && kt + 1 < nkt) stash(buf ^ 1, kt + 1);
-      float av[TM], bv[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) av[i] = As[buf][kk + fk][fa + i * 32];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bv[j] = Bs[buf][kk + fk][fb + j * 32];
+      // scheduling fence: keeps "next fragments' LDS reads" ahead of this k-pair's MFMAs (hipcc otherwise sinks the
+      // reads behind the MFMAs and waits lgkmcnt(0) in front of every group)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
@@ -405,8 +424,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
 }
 
 template <int OP, int BM, int BN>
-int launch(const P& p, int nz, hipStream_t st) {
-  dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, nz);
+int launch(const P& p0, int nz, hipStream_t st) {
+  P p = p0;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  dim3 grid(p.tiles_n * ((p.M + BM - 1) / BM), 1, nz);
   ICK_LAUNCH((igemm_f32_kernel<OP, BM, BN>), grid, dim3(NT), 0, st, p);
   return ick::launch_status("igemm_f32");
 }

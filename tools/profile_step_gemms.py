@@ -15,7 +15,7 @@ from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models  # no
 from imagecaptioner_amd.utils.seeded_init import synthetic_batch  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-OPN = ["NT", "NN", "TN", "CONV_FWD", "CONV_FWD_C4", "CONV_DGRAD", "CONV_WGRAD"]
+OPN = ["NT", "NN", "TN", "CONV_FWD", "CONV_FWD_C4", "CONV_DGRAD", "CONV_WGRAD", "CONV_DGRAD_S2"]
 records = []
 orig = ops.gemm_raw
 
