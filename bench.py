@@ -32,6 +32,16 @@ BATCH = 64
 VOCAB, T1 = 5000, 16
 
 
+def measured_traffic(batch: int):
+    """HBM bytes per step (one hipGraph replay) from the committed PMC run (profiles/r01_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 fetch correction); None for other batch sizes."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+    except (OSError, ValueError):
+        return None
+    return t["hbm_bytes_per_step_corrected"] if batch == BATCH else None
+
+
 def cpu_baseline(batch: int = 16):
     """The oracle (CPU restatement, plain PyTorch fp32) timed on this box's host cores on a bounded sample of the
     same workload: teacher fwd + student fwd (train-mode BN, dropout off) + KD loss + backward, single ViT pass."""
@@ -145,7 +155,7 @@ def main():
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "final_loss": round(loss["total_loss"], 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": None,
+                         "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": measured_traffic(args.batch),
                          "note": "whole step: 28.4 algorithmic GFLOP/image (SURVEY 8d) x batch / device time per step "
                                  "(HIP events on the launch stream); denominator = fp32 MFMA peak (exact-fp32 path)"},
         }
