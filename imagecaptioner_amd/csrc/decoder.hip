@@ -20,26 +20,32 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
-// one workgroup per image b; L positions (49), E features
-__global__ __launch_bounds__(NT) void attn_step_fwd_kernel(const float* __restrict__ Uf, const float* __restrict__ hW,
-                                                          const float* __restrict__ feats, float* __restrict__ w_out,
-                                                          float* __restrict__ ctx, int L, int E) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // [L] scores/weights + [E] hW row
+// one 1024-thread workgroup (16 waves) per image b; L positions (49), E features (<= 1024).
+// Only B workgroups exist per step, so the work of one image is spread over as many waves as a CU takes:
+// scores: one wave per position (lanes stride the E axis); context: threads = (feature e) x (position group).
+constexpr int ANT = 1024;
+
+__global__ __launch_bounds__(ANT) void attn_step_fwd_kernel(const float* __restrict__ Uf, const float* __restrict__ hW,
+                                                           const float* __restrict__ feats, float* __restrict__ w_out,
+                                                           float* __restrict__ ctx, int L, int E) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [Lp] scores/weights, [E] hW row, [ng*E] partial ctx
+  const int Lp = (L + 3) & ~3;
   float* sc = sh;
-  float* hrow = sh + ((L + 3) & ~3);
+  float* hrow = sh + Lp;
+  float* part = hrow + E;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* U = Uf + (long)b * L * E;
   const float* F = feats + (long)b * L * E;
-  for (int e = tid; e < E; e += NT) hrow[e] = hW[(long)b * E + e];
+  for (int e = tid; e < E; e += ANT) hrow[e] = hW[(long)b * E + e];
   __syncthreads();
-  for (int j = wave; j < L; j += NT / 64) {
+  for (int j = wave; j < L; j += ANT / 64) {
     float s = 0.f;
     for (int e = lane; e < E; e += 64) s += tanhf(U[(long)j * E + e] + hrow[e]);
     s = wave_sum(s);
     if (lane == 0) sc[j] = s;
   }
   __syncthreads();
-  if (wave == 0) {  // softmax over L <= 64*k positions
+  if (wave == 0) {  // softmax over the L positions
     float mx = -INFINITY;
     for (int j = lane; j < L; j += 64) mx = fmaxf(mx, sc[j]);
 #pragma unroll
@@ -55,29 +61,38 @@ __global__ __launch_bounds__(NT) void attn_step_fwd_kernel(const float* __restri
     }
   }
   __syncthreads();
-  for (int e = tid; e < E; e += NT) {
+  const int ng = ANT / E;                       // position groups (4 for E=256)
+  const int e = tid % E, jg = tid / E;
+  if (jg < ng) {
     float a = 0.f;
-    for (int j = 0; j < L; ++j) a += sc[j] * F[(long)j * E + e];
-    ctx[(long)b * E + e] = a;
+    for (int j = jg; j < L; j += ng) a += sc[j] * F[(long)j * E + e];
+    part[jg * E + e] = a;
+  }
+  __syncthreads();
+  if (tid < E) {
+    float a = 0.f;
+    for (int g = 0; g < ng; ++g) a += part[g * E + tid];   // fixed order: deterministic
+    ctx[(long)b * E + tid] = a;
   }
 }
 
 // adjoint of attn_step_fwd for one step: dUf += dpre, dfeats += w (x) dctx, dhW = sum_j dpre
-__global__ __launch_bounds__(NT) void attn_step_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ w,
-                                                          const float* __restrict__ Uf, const float* __restrict__ hW,
-                                                          const float* __restrict__ feats, float* __restrict__ dUf,
-                                                          float* __restrict__ dfeats, float* __restrict__ dhW, int L, int E) {
-  extern __shared__ __attribute__((aligned(16))) float sh[];  // [L] ds, [L] w, [E] dctx
+__global__ __launch_bounds__(ANT) void attn_step_bwd_kernel(const float* __restrict__ dctx, const float* __restrict__ w,
+                                                           const float* __restrict__ Uf, const float* __restrict__ hW,
+                                                           const float* __restrict__ feats, float* __restrict__ dUf,
+                                                           float* __restrict__ dfeats, float* __restrict__ dhW, int L, int E) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];  // [Lp] ds, [Lp] w, [E] dctx, [ng*E] partial dhW
   const int Lp = (L + 3) & ~3;
   float* ds = sh;
   float* wl = sh + Lp;
   float* dc = sh + 2 * Lp;
+  float* part = dc + E;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long base = (long)b * L * E;
-  for (int e = tid; e < E; e += NT) dc[e] = dctx[(long)b * E + e];
-  for (int j = tid; j < L; j += NT) wl[j] = w[(long)b * L + j];
+  for (int e = tid; e < E; e += ANT) dc[e] = dctx[(long)b * E + e];
+  for (int j = tid; j < L; j += ANT) wl[j] = w[(long)b * L + j];
   __syncthreads();
-  for (int j = wave; j < L; j += NT / 64) {  // dw_j = <dctx, f_j>
+  for (int j = wave; j < L; j += ANT / 64) {  // dw_j = <dctx, f_j>
     float s = 0.f;
     for (int e = lane; e < E; e += 64) s += dc[e] * feats[base + (long)j * E + e];
     s = wave_sum(s);
@@ -91,10 +106,12 @@ __global__ __launch_bounds__(NT) void attn_step_bwd_kernel(const float* __restri
     for (int j = lane; j < L; j += 64) ds[j] = wl[j] * (ds[j] - d);
   }
   __syncthreads();
-  for (int e = tid; e < E; e += NT) {
+  const int ng = ANT / E;
+  const int e = tid % E, jg = tid / E;
+  if (jg < ng) {
     const float h = hW[(long)b * E + e], dce = dc[e];
     float acc = 0.f;
-    for (int j = 0; j < L; ++j) {
+    for (int j = jg; j < L; j += ng) {
       const long o = base + (long)j * E + e;
       // d tanh = sech^2 = 4 e^{-2|x|} / (1 + e^{-2|x|})^2 : relative accuracy also where tanh saturates
       // (1 - tanh^2 loses all digits there)
@@ -104,7 +121,13 @@ __global__ __launch_bounds__(NT) void attn_step_bwd_kernel(const float* __restri
       dfeats[o] += wl[j] * dce;
       acc += dp;
     }
-    dhW[(long)b * E + e] = acc;
+    part[jg * E + e] = acc;
+  }
+  __syncthreads();
+  if (tid < E) {
+    float a = 0.f;
+    for (int g = 0; g < ng; ++g) a += part[g * E + tid];
+    dhW[(long)b * E + tid] = a;
   }
 }
 
@@ -179,9 +202,9 @@ extern "C" {
 
 int ick_attn_step_fwd(const float* Uf, const float* hW, const float* feats, float* w_out, float* ctx, int B, int L, int E,
                       void* stream) {
-  ICK_REQUIRE(Uf && hW && feats && w_out && ctx && B > 0 && L > 0 && E > 0, "ick_attn_step_fwd: bad arguments");
-  const size_t sh = (((L + 3) & ~3) + E) * sizeof(float);
-  ICK_LAUNCH(attn_step_fwd_kernel, dim3(B), dim3(NT), sh, ST, Uf, hW, feats, w_out, ctx, L, E);
+  ICK_REQUIRE(Uf && hW && feats && w_out && ctx && B > 0 && L > 0 && E > 0 && E <= ANT, "ick_attn_step_fwd: bad arguments (E <= 1024)");
+  const size_t sh = (((L + 3) & ~3) + E + (size_t)(ANT / E) * E) * sizeof(float);
+  ICK_LAUNCH(attn_step_fwd_kernel, dim3(B), dim3(ANT), sh, ST, Uf, hW, feats, w_out, ctx, L, E);
   return ick::launch_status("attn_step_fwd");
 }
 
@@ -189,8 +212,9 @@ int ick_attn_step_bwd(const float* dctx, const float* w, const float* Uf, const 
                       float* dfeats, float* dhW, int B, int L, int E, void* stream) {
   ICK_REQUIRE(dctx && w && Uf && hW && feats && dUf && dfeats && dhW && B > 0 && L > 0 && E > 0,
               "ick_attn_step_bwd: bad arguments");
-  const size_t sh = (2 * ((L + 3) & ~3) + E) * sizeof(float);
-  ICK_LAUNCH(attn_step_bwd_kernel, dim3(B), dim3(NT), sh, ST, dctx, w, Uf, hW, feats, dUf, dfeats, dhW, L, E);
+  ICK_REQUIRE(E <= ANT, "ick_attn_step_bwd: E <= 1024");
+  const size_t sh = (2 * ((L + 3) & ~3) + E + (size_t)(ANT / E) * E) * sizeof(float);
+  ICK_LAUNCH(attn_step_bwd_kernel, dim3(B), dim3(ANT), sh, ST, dctx, w, Uf, hW, feats, dUf, dfeats, dhW, L, E);
   return ick::launch_status("attn_step_bwd");
 }
 

@@ -244,6 +244,62 @@ class KDTrainer:
         v = self.out5.detach().cpu().tolist()
         return {"total_loss": v[0], "ce_loss": v[1], "token_kd_loss": v[2], "feature_kd_loss": v[3], "hidden_kd_loss": v[4]}
 
+    # ------------------------------------------------------------------ checkpoint (reference .pth layout)
+    def _optimizer_param_groups(self):
+        """parameter lists in the reference optimizer's order (train_student_kd.py:219-234): all encoder params
+        (frozen ones included, they simply never get state), decoder params, refinement + every projector's params."""
+        other = list(self.student.attention_refinement.parameters()) if self.student.use_attention_refinement else []
+        for pr in self.projectors.values():
+            other.extend(list(pr.parameters()))
+        return [list(self.student.encoder.parameters()), list(self.student.decoder.parameters()), other]
+
+    def optimizer_state_dict(self) -> dict:
+        """torch.optim.AdamW-compatible state dict rebuilt from the flat moment buffers, so that
+        `AdamW(groups).load_state_dict(...)` of a reference-side tool accepts it."""
+        where = {id(p): (o, n) for p, o, n in self.flat.metas}
+        state, groups, idx = {}, [], 0
+        lr_mult = (0.1, 1.0, 1.0)
+        for gi, plist in enumerate(self._optimizer_param_groups()):
+            ids = []
+            for p in plist:
+                if id(p) in where and self.step_count > 0:
+                    o, n = where[id(p)]
+                    shape4 = p.dim() == 4
+                    view = (lambda flat: flat[o:o + n].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
+                            if shape4 else flat[o:o + n].view(p.shape))
+                    state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": view(self.flat.exp_avg).clone(),
+                                  "exp_avg_sq": view(self.flat.exp_avg_sq).clone()}
+                ids.append(idx)
+                idx += 1
+            base = self.lr * lr_mult[gi]
+            groups.append({"lr": self.eta_min + (base - self.eta_min) * self._f_now, "betas": self.betas, "eps": self.eps,
+                           "weight_decay": self.wd, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                           "differentiable": False, "fused": None, "decoupled_weight_decay": True, "initial_lr": base,
+                           "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def scheduler_state_dict(self) -> dict:
+        ep = self.epoch + self.batch_idx / max(1, self.batches_per_epoch)
+        return {"T_0": 5, "T_i": 5, "T_mult": 2, "eta_min": self.eta_min, "T_cur": ep, "last_epoch": ep,
+                "base_lrs": [self.lr * 0.1, self.lr, self.lr]}
+
+    def checkpoint(self, epoch: int, val_loss: float = float("nan"), val_bleu: float = float("nan"),
+                   model_config: Optional[dict] = None) -> dict:
+        """The dict the reference writes with torch.save (train_student_kd.py:359-380): same keys, so
+        evaluate_student.py / a resumed reference run can read a checkpoint produced here."""
+        s, L = self.student, self.loss
+        mc = model_config or {"embed_size": s.embed_size, "hidden_size": s.hidden_size, "num_layers": s.decoder.num_layers,
+                              "dropout": s.decoder.output_projection[2].p}
+        contig = lambda sd: {k: (v.detach().contiguous().cpu() if torch.is_tensor(v) else v) for k, v in sd.items()}
+        return {"epoch": epoch, "student_state_dict": contig(s.state_dict()),
+                "projectors_state_dict": {k: contig(v.state_dict()) for k, v in self.projectors.items()},
+                "optimizer_state_dict": self.optimizer_state_dict(), "scheduler_state_dict": self.scheduler_state_dict(),
+                "val_loss": val_loss, "val_bleu": val_bleu, "vocab_size": s.vocab_size, "model_config": mc,
+                "distillation_config": {"alpha": L.alpha, "beta": L.beta, "gamma": L.gamma, "temperature": L.temperature}}
+
+    def save_checkpoint(self, path: str, epoch: int, **kw) -> None:
+        torch.save(self.checkpoint(epoch, **kw), path)
+
 
 def build_kd_models(vocab_size=5000, embed_size=256, hidden_size=512, num_layers=2, dropout=0.3, refine=True,
                     teacher_embed=512, teacher_heads=8, teacher_layers=4, teacher_dropout=0.15, device="cuda", seeds=(0, 1, 2)):
