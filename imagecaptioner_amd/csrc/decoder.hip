@@ -194,6 +194,69 @@ __global__ void argmax_rows_kernel(const float* __restrict__ x, long* __restrict
   }
 }
 
+// beam-search expansion (reference: CaptioningTeacher.caption_image, /root/reference/src/teacher_model.py:170-179):
+// candidate[b][v] = scores[b] + log_softmax(logits[b])[v]; the k best of the flattened (b,v) space, best first
+// (ties: lower flat index).  One 1024-thread workgroup: Bl*V is ~25k.  No host round trip between the softmax
+// and the selection; the caller copies 2k numbers back per step instead of the reference's per-candidate .item()s.
+__global__ __launch_bounds__(1024) void beam_topk_kernel(const float* __restrict__ logits, const float* __restrict__ scores,
+                                                        int Bl, int V, int k, float* __restrict__ out_vals,
+                                                        long* __restrict__ out_idx) {
+  __shared__ float lse[64];
+  __shared__ float rv[16];
+  __shared__ long ri[16];
+  __shared__ long chosen[32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int b = 0; b < Bl; ++b) {                      // log-sum-exp of every live beam's row
+    const float* row = logits + (long)b * V;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 1024) mx = fmaxf(mx, row[v]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) rv[wave] = mx;
+    __syncthreads();
+    mx = rv[0];
+    for (int w = 1; w < 16; ++w) mx = fmaxf(mx, rv[w]);
+    __syncthreads();
+    float s = 0.f;
+    for (int v = tid; v < V; v += 1024) s += expf(row[v] - mx);
+    s = wave_sum(s);
+    if (lane == 0) rv[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < 16; ++w) t += rv[w];
+      lse[b] = mx + logf(t);
+    }
+    __syncthreads();
+  }
+  const long total = (long)Bl * V;
+  for (int r = 0; r < k; ++r) {
+    float best = -INFINITY; long bi = total;
+    for (long i = tid; i < total; i += 1024) {
+      bool taken = false;
+      for (int c = 0; c < r; ++c) taken |= (chosen[c] == i);
+      if (taken) continue;
+      const int b = (int)(i / V);
+      const float val = scores[b] + (logits[i] - lse[b]);
+      if (val > best || (val == best && i < bi) || bi == total) { best = val; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o); const long oi = __shfl_xor(bi, o);
+      if (oi != total && (bi == total || ov > best || (ov == best && oi < bi))) { best = ov; bi = oi; }
+    }
+    if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+      float bb = rv[0]; long ii = ri[0];
+      for (int w = 1; w < 16; ++w)
+        if (ri[w] != total && (ii == total || rv[w] > bb || (rv[w] == bb && ri[w] < ii))) { bb = rv[w]; ii = ri[w]; }
+      chosen[r] = ii; out_vals[r] = bb; out_idx[r] = ii;
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 #define ST static_cast<hipStream_t>(stream)
@@ -239,6 +302,14 @@ int ick_argmax_rows(const float* x, int64_t* ids, int64_t rows, int V, int64_t l
   long g = (rows + 3) / 4; if (g > 2048) g = 2048;
   ICK_LAUNCH(argmax_rows_kernel, dim3((int)g), dim3(NT), 0, ST, x, (long*)ids, (long)rows, V, (long)ld);
   return ick::launch_status("argmax_rows");
+}
+
+int ick_beam_topk(const float* logits, const float* scores, int Bl, int V, int k, float* out_vals, int64_t* out_idx,
+                  void* stream) {
+  ICK_REQUIRE(logits && scores && out_vals && out_idx && Bl > 0 && Bl <= 64 && V > 0 && k > 0 && k <= 32 && (long)Bl * V >= k,
+              "ick_beam_topk: bad arguments (Bl <= 64, k <= 32)");
+  ICK_LAUNCH(beam_topk_kernel, dim3(1), dim3(1024), 0, ST, logits, scores, Bl, V, k, out_vals, (long*)out_idx);
+  return ick::launch_status("beam_topk");
 }
 
 }  // extern "C"

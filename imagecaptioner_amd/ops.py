@@ -173,7 +173,7 @@ def layernorm_bwd(dy, x, g, mean, rstd, dg: Optional[torch.Tensor], db: Optional
 # ----------------------------------------------------------------------------- attention core (unfused: GEMM + softmax + GEMM)
 def attention_fwd(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, koff: int, kld: int, v: torch.Tensor, voff: int,
                   vld: int, B: int, H: int, Lq: int, Lk: int, d: int, causal: bool = False, p_drop: float = 0.0,
-                  seed: int = 0):
+                  seed: int = 0, kv_batch_stride: Optional[int] = None):
     """softmax(Q K^T / sqrt(d)) V per (batch, head) [dropout on the probabilities when p_drop > 0].  q/k/v are 2-D row matrices [(B*L)][ld] in which head h of
     the operand starts at column off + h*d (packed in_proj outputs).  Returns (O [B*Lq][H*d], P [B,H,Lq,Lkp]) with
     the probability rows padded to Lkp = roundup4(Lk) (pad columns are zero)."""
@@ -182,8 +182,10 @@ def attention_fwd(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, koff: i
     P = empty(B, H, Lq, Lkp, device=q.device)
     O = empty(B * Lq, E, device=q.device)
     fs = 4  # bytes per float
+    kbs = Lk * kld if kv_batch_stride is None else kv_batch_stride   # 0: every batch entry attends to the SAME keys
+    vbs = Lk * vld if kv_batch_stride is None else kv_batch_stride
     gemm_raw(OP_NT, q.data_ptr() + qoff * fs, k.data_ptr() + koff * fs, P.data_ptr(), Lq, Lk, d, qld, kld, Lkp,
-             batch=(B, H), strides=(Lq * qld, d, Lk * kld, d, H * Lq * Lkp, Lq * Lkp))
+             batch=(B, H), strides=(Lq * qld, d, kbs, d, H * Lq * Lkp, Lq * Lkp))
     check(_lib.lib().ick_softmax_rows(P.data_ptr(), B * H * Lq, Lk, Lkp, 1.0 / math.sqrt(d), int(causal), Lq, _st()),
           "ick_softmax_rows")
     Pd = P
@@ -191,7 +193,7 @@ def attention_fwd(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, koff: i
         Pd = torch.empty_like(P)
         dropout(P, Pd, p_drop, seed)
     gemm_raw(OP_NN, Pd.data_ptr(), v.data_ptr() + voff * fs, O.data_ptr(), Lq, d, Lk, Lkp, vld, E,
-             batch=(B, H), strides=(H * Lq * Lkp, Lq * Lkp, Lk * vld, d, Lq * E, d))
+             batch=(B, H), strides=(H * Lq * Lkp, Lq * Lkp, vbs, d, Lq * E, d))
     return O, P
 
 
@@ -449,6 +451,16 @@ def _skinny_splitk(M: int, N: int, K: int) -> int:
         return 1
     tiles = (N + 63) // 64
     return max(1, min(K // 32, 256 // max(tiles, 1)))
+
+
+def beam_topk(logits: torch.Tensor, scores: torch.Tensor, k: int):
+    """k best (value, flat index b*V+v) of scores[b] + log_softmax(logits[b]) — device-side beam expansion."""
+    Bl, V = logits.shape
+    vals = empty(k, device=logits.device)
+    idx = torch.empty(k, dtype=torch.int64, device=logits.device)
+    check(_lib.lib().ick_beam_topk(logits.data_ptr(), scores.data_ptr(), Bl, V, k, vals.data_ptr(), idx.data_ptr(), _st()),
+          "ick_beam_topk")
+    return vals, idx
 
 
 def gemm_nt(x: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Tensor, *, bias=None, residual=None,

@@ -150,15 +150,18 @@ class CaptioningTeacher(nn.Module):
         return ops.linear_fwd(hnn._c(vit_tokens), self.encoder_projection.weight, self.encoder_projection.bias)
 
     @torch.no_grad()
-    def decode(self, memory, captions):
-        """Transformer decoder over teacher-forced captions (T,B) with memory (B,197,E) -> logits (T,B,V)
-        (reference :86-104, eval mode: dropout off).  Internally batch-first; the final GEMM writes (T,B,V)."""
+    def _decode_hidden(self, memory, captions):
+        """pre_output_norm(decoder(embedding + PE, memory)) for teacher-forced captions (T,B), batch-first rows
+        [(B*T)][E] (reference :86-102, eval mode: dropout off).  memory (Bm,197,E) with Bm == B, or Bm == 1 for one
+        image shared by all B sequences (beam search: the cross-attention K/V are then projected once and every
+        beam attends to the same keys through a zero batch stride — the reference copies memory per beam, :143)."""
         if self.training:
             raise NotImplementedError("the HIP teacher is forward-only/eval (frozen in KD, distillation_utils.py:259-266)")
         T, B = captions.shape
-        E, H, V = memory.shape[-1], self.num_heads, self.vocab_size
-        L = memory.shape[1]
-        mem2 = hnn._c(memory).view(B * L, E)
+        E, H = memory.shape[-1], self.num_heads
+        Bm, L = memory.shape[0], memory.shape[1]
+        assert Bm in (1, B)
+        mem2 = hnn._c(memory).view(Bm * L, E)
         ids_bt = captions.t().contiguous()                                              # (B,T) token ids
         x2 = ops.embedding_fwd(ids_bt, self.embedding.weight, pe=self.pos_encoder.table(), per_pos=-T).view(B * T, E)
         for lyr in self.decoder.layers:
@@ -167,8 +170,9 @@ class CaptioningTeacher(nn.Module):
             x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, sa.out_proj.weight, sa.out_proj.bias, residual=x2),
                                          lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, save=False)
             q = ops.linear_fwd(x2, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
-            kv = ops.linear_fwd(mem2, ca.in_proj_weight[E:], ca.in_proj_bias[E:])      # [(B*L)][2E]
-            o, _ = ops.attention_fwd(q, 0, E, kv, 0, 2 * E, kv, E, 2 * E, B, H, T, L, E // H, False)
+            kv = ops.linear_fwd(mem2, ca.in_proj_weight[E:], ca.in_proj_bias[E:])      # [(Bm*L)][2E]
+            o, _ = ops.attention_fwd(q, 0, E, kv, 0, 2 * E, kv, E, 2 * E, B, H, T, L, E // H, False,
+                                     kv_batch_stride=None if Bm == B else 0)
             x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, ca.out_proj.weight, ca.out_proj.bias, residual=x2),
                                          lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, save=False)
             h = ops.linear_fwd(x2, lyr.linear1.weight, lyr.linear1.bias, act=ACT_RELU)
@@ -176,6 +180,15 @@ class CaptioningTeacher(nn.Module):
                                          lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, save=False)
         xn, _, _ = ops.layernorm_fwd(x2, self.pre_output_norm.weight, self.pre_output_norm.bias, self.pre_output_norm.eps,
                                      save=False)
+        return xn
+
+    @torch.no_grad()
+    def decode(self, memory, captions):
+        """Transformer decoder over teacher-forced captions (T,B) with memory (B,197,E) -> logits (T,B,V)
+        (reference :86-104).  Internally batch-first; the final GEMM writes (T,B,V) directly."""
+        T, B = captions.shape
+        E, V = memory.shape[-1], self.vocab_size
+        xn = self._decode_hidden(memory, captions)
         logits = ops.empty(T, B, V, device=memory.device)
         # rows of xn are (b,t); batch the GEMM over b so that C[t][b][:] is written in place (no transpose pass)
         ops.gemm_raw(ops.OP_NT, xn.data_ptr(), self.fc_out.weight.data_ptr(), logits.data_ptr(), T, V, E, E, E, B * V,
@@ -183,11 +196,68 @@ class CaptioningTeacher(nn.Module):
         return logits
 
     @torch.no_grad()
+    def decode_last(self, memory, captions):
+        """logits (B,V) of the LAST position only (beam search needs nothing else, reference :168)."""
+        T, B = captions.shape
+        E, V = memory.shape[-1], self.vocab_size
+        xn = self._decode_hidden(memory, captions)
+        logits = ops.empty(B, V, device=memory.device)
+        ops.gemm_raw(ops.OP_NT, xn.data_ptr() + (T - 1) * E * 4, self.fc_out.weight.data_ptr(), logits.data_ptr(), B, V, E,
+                     T * E, E, V, bias=self.fc_out.bias.data_ptr())
+        return logits
+
+    @torch.no_grad()
     def forward(self, images, captions):
         memory = self.project_memory(self.encoder.forward_features(images))
         return self.decode(memory, captions)
 
+    @torch.no_grad()
     def caption_image(self, image, vocabulary, max_length: int = 20, beam_size: int = 5, length_penalty: float = 0.6,
                       early_stopping: bool = True, num_return_sequences: int = 1):
-        raise NotImplementedError("beam-search captioning (reference :108-252) is SURVEY.md §8(f) row N1, scheduled after "
-                                  "the KD step; not part of the train-step hot path")
+        """Beam-search captioning, list of strings (reference :108-252).  Same search: every live beam is expanded
+        with log-probabilities, the `beam` best (beam, token) pairs survive, a pair ending in <END> leaves the beam
+        as a finished hypothesis scored score / ((5+len)/6)^alpha (len counts <START> and <END>), and the beam width
+        shrinks by the number of hypotheses that finished.  The decoder is re-run on the growing prefixes like the
+        reference does (<= 20 tokens x <= 5 beams), entirely on device; per step ONE (beam x 2)-number copy comes back
+        to the host instead of three scalar syncs per candidate."""
+        self.eval()
+        device = next(self.parameters()).device
+        start_id = vocabulary.stoi.get("<START>", vocabulary.stoi.get("<UNK>"))
+        end_id = vocabulary.stoi.get("<END>", None)
+        assert start_id is not None, "Vocabulary must define <START> or <UNK>."
+        n_return = min(num_return_sequences, beam_size)
+        if image.dim() == 3:
+            image = image.unsqueeze(0)
+        memory = self.project_memory(self.encoder.forward_features(image.to(device)))      # (1,197,E), shared by beams
+        V = self.vocab_size
+        penalty = (lambda n: ((5.0 + n) / 6.0) ** length_penalty) if length_penalty > 0 else (lambda n: 1.0)
+        beams = [[start_id] for _ in range(beam_size)]
+        scores = [0.0] + [float("-inf")] * (beam_size - 1)           # only beam 0 is real before the first expansion
+        done = []                                                     # (tokens, normalised score), in finishing order
+        for _ in range(max_length):
+            width = len(beams)
+            tokens = torch.tensor(beams, dtype=torch.int64, device=device).t().contiguous()      # (t, width)
+            logits = self.decode_last(memory, tokens)
+            vals, flat = ops.beam_topk(logits, torch.tensor(scores, dtype=torch.float32, device=device), width)
+            vals, flat = vals.tolist(), flat.tolist()                 # the step's only host synchronisation
+            grown, grown_scores = [], []
+            for score, f in zip(vals, flat):
+                seq = beams[f // V] + [f % V]
+                if end_id is not None and seq[-1] == end_id:
+                    done.append((seq, score / penalty(len(seq))))
+                else:
+                    grown.append(seq)
+                    grown_scores.append(score)
+            if not grown:
+                break
+            beams, scores = grown, grown_scores
+        if not done:
+            done = [(seq, sc / penalty(len(seq))) for seq, sc in zip(beams, scores)]
+        done.sort(key=lambda h: h[1], reverse=True)                   # stable: ties keep finishing order
+        captions = []
+        for seq, _ in done[:n_return]:
+            body = seq[1:] if seq and seq[0] == start_id else seq
+            if end_id is not None and end_id in body:
+                body = body[:body.index(end_id)]
+            captions.append(" ".join(vocabulary.itos[i] for i in body))
+        return captions

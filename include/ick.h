@@ -130,6 +130,8 @@ int ick_lstm_cell_fwd(const float* G, const float* b_ih, const float* b_hh, cons
 int ick_lstm_cell_bwd(const float* dh_a, const float* dh_b, const float* dc_in, const float* gates, const float* c,
                       const float* c_prev, float* dG, float* dc_prev, int B, int H, void* stream);
 int ick_argmax_rows(const float* x, int64_t* ids, int64_t rows, int V, int64_t ld, void* stream); /* greedy token (student_model.py:369) */
+int ick_beam_topk(const float* logits, const float* scores, int Bl, int V, int k, float* out_vals, int64_t* out_idx,
+                  void* stream); /* scores[b] + log_softmax(logits[b]) -> k best flat (b*V+v) candidates (teacher_model.py:170-179) */
 
 /* ------------------------------------------------------------------ KD losses, fused forward + backward
  * DistillationLoss (distillation_utils.py:8-200).  Gradients are produced in the same pass as the loss terms,

@@ -278,6 +278,30 @@ def golden_kd_step():
         d_projw=(pj["feature_projection.0.weight"].detach() - pj_before)[::16, ::16])
 
 
+# ------------------------------------------------------------------ (9) teacher beam search
+def golden_beam():
+    t = build_teacher()
+    vocab = _Vocab(V)
+    images, _ = synthetic_batch(3, V, T1, seed=4321)
+    outs = {}
+    for b in range(3):
+        for (beam, lp, nret, tag) in ((5, 0.6, 3, "b5"), (3, 0.0, 1, "b3"), (1, 0.6, 1, "b1")):
+            caps = t.caption_image(images[b], vocab, max_length=12, beam_size=beam, length_penalty=lp,
+                                   num_return_sequences=nret)
+            outs[f"img{b}_{tag}"] = np.array(caps)
+    # with key-seeded random weights <END> never wins, so the finishing / length-penalty / shrinking-beam logic
+    # (teacher_model.py:198-229) is exercised by raising the <END> bias of fc_out (same shift on both sides in the test)
+    for bias in (12.0, 10.5):
+        with torch.no_grad():
+            t.fc_out.bias[2] += bias
+        for b in range(3):
+            caps = t.caption_image(images[b], vocab, max_length=12, beam_size=5, length_penalty=0.6, num_return_sequences=5)
+            outs[f"img{b}_b5_end{bias}"] = np.array(caps)
+        with torch.no_grad():
+            t.fc_out.bias[2] -= bias
+    npz("teacher_beam.npz", batch_seed=4321, **outs)
+
+
 def golden_param_counts():
     """SURVEY.md §0 fact 10 — pins the architecture sizes."""
     torch.manual_seed(0)
@@ -296,9 +320,9 @@ def golden_param_counts():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step"]
+    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "beam"]
     fns = {"counts": golden_param_counts, "losses": golden_losses, "projector": golden_projector,
            "refinement": golden_refinement, "decoders": golden_decoders, "cfg1": golden_cfg1,
-           "teacher": golden_teacher, "kd_step": golden_kd_step}
+           "teacher": golden_teacher, "kd_step": golden_kd_step, "beam": golden_beam}
     for w in which:
         fns[w]()
