@@ -133,6 +133,7 @@ def test_create_feature_projectors_and_helpers():
 
     class V:
         itos = {0: "<PAD>", 1: "<START>", 2: "<END>", 3: "<UNK>", 4: "a", 5: "dog", 6: "runs"}
+        stoi = {w: i for i, w in itos.items()}
     assert D.compute_bleu_score([1, 4, 5, 2, 0], [1, 4, 5, 6, 2], V) == pytest.approx(2 / 3)
     assert D.compute_bleu_score([4], [0, 1, 2], V) == 0.0
     out = io.StringIO()
