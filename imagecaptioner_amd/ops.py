@@ -18,6 +18,8 @@ _F32 = torch.float32
 
 
 def _st() -> int:
+    if not torch.cuda.is_available():
+        raise RuntimeError("the HIP path needs an MI355X (no CPU fallback exists)")
     return torch.cuda.current_stream().cuda_stream
 
 
