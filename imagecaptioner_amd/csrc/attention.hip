@@ -1,0 +1,175 @@
+// attention.hip — fused forward attention softmax(Q K^T / sqrt(d)) V on the fp32 matrix cores (gfx950), d = 64.
+//
+// Used by the frozen teacher (no backward needed): ViT-S/16 self-attention (197 tokens x 6 heads,
+// timm blocks; /root/reference/src/teacher_model.py:82) and the Transformer-decoder self/cross attention
+// (nn.MultiheadAttention inside nn.TransformerDecoderLayer, /root/reference/src/teacher_model.py:60-67), and by
+// the student's refinement block in eval mode.  The (B,H,Lq,Lk) score matrix never reaches HBM
+// (unfused: 2 x 60 MB per ViT layer written and re-read).
+//
+// Structure (64-wide wavefronts, v_mfma_f32_32x32x2_f32, exact fp32):
+//   * one workgroup per (batch, head); wave w owns queries [32w, 32w+32) of that head;
+//   * keys/values stream through LDS in chunks of 32 keys (double buffered, register-staged prefetch);
+//   * S^T = K Q^T ("swapped" product): the accumulator of a 32x32 tile then holds, per lane, ONE query column
+//     and 16 of the 32 keys in its registers, so the online-softmax row statistics are register reductions plus a
+//     single lane<->lane+32 exchange, and the per-query rescale is a per-lane scalar;
+//   * O^T += V^T P^T takes that accumulator DIRECTLY as the MFMA B operand: the k-pairing of the 32x32x2 MFMA is
+//     chosen as (key held by lane half 0, key held by lane half 1) of register r, so no data moves between the
+//     two products (the V^T fragment is read from LDS in the matching key order);
+//   * K chunk rows are padded to 65 floats (the A-fragment read walks keys across lanes), V rows to 64.
+#include "ick_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int D = 64;       // head dim
+constexpr int KC = 32;      // keys per chunk
+constexpr int KP = D + 1;   // K row pitch in LDS
+
+struct AP {
+  const float* q; const float* k; const float* v; float* o;
+  long qld, kld, vld, old;          // row pitches (elements)
+  long qbs, kbs, vbs, obs;          // batch strides (elements); head h adds h*D columns
+  int H, Lq, Lk, causal;
+  float scale;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AP p) {
+  __shared__ __attribute__((aligned(16))) float Ks[2][KC][KP];
+  __shared__ __attribute__((aligned(16))) float Vs[2][KC][D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const float* Q = p.q + b * p.qbs + h * D;
+  const float* K = p.k + b * p.kbs + h * D;
+  const float* V = p.v + b * p.vbs + h * D;
+  float* O = p.o + b * p.obs + h * D;
+  const int q0 = (blockIdx.y * NW + wave) * 32;
+  const int qrow = q0 + col;                       // this lane's query
+  const bool qok = qrow < p.Lq;
+
+  // B operand of S^T = K Q^T: lane (query col, half) needs Q[query][d = 2kk + half], kk = 0..31, pre-scaled
+  float qf[32];
+#pragma unroll
+  for (int kk = 0; kk < 32; ++kk) qf[kk] = qok ? Q[(long)qrow * p.qld + 2 * kk + half] * p.scale : 0.f;
+
+  f32x16 ot[2];                                    // O^T tiles: rows d = 32t + (r&3)+8(r>>2)+4half, column = query
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
+  float mrun = -INFINITY, lrun = 0.f;
+
+  // chunk staging: NW*64 threads move 32 keys x 64 floats of K and V each (float4 per thread per pass)
+  constexpr int NTH = NW * 64;
+  constexpr int F4 = KC * D / 4;                   // 512 float4 per operand
+  constexpr int PASS = (F4 + NTH - 1) / NTH;
+  float4 rk[PASS], rv[PASS];
+  const int nchunks = (p.Lk + KC - 1) / KC;
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const int f = tid + i * NTH;
+      const int key = c * KC + f / (D / 4), d4 = (f % (D / 4)) * 4;
+      const bool ok = f < F4 && key < p.Lk;
+      rk[i] = ok ? *reinterpret_cast<const float4*>(K + (long)key * p.kld + d4) : make_float4(0, 0, 0, 0);
+      rv[i] = ok ? *reinterpret_cast<const float4*>(V + (long)key * p.vld + d4) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const int f = tid + i * NTH;
+      if (f < F4) {
+        const int key = f / (D / 4), d4 = (f % (D / 4)) * 4;
+        Ks[buf][key][d4 + 0] = rk[i].x; Ks[buf][key][d4 + 1] = rk[i].y;
+        Ks[buf][key][d4 + 2] = rk[i].z; Ks[buf][key][d4 + 3] = rk[i].w;
+        *reinterpret_cast<float4*>(&Vs[buf][key][d4]) = rv[i];
+      }
+    }
+  };
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) fetch(c + 1);
+    // ---- S^T (keys x queries) = K_chunk (32 x 64) . Q^T (64 x 32)
+    f32x16 st;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) st[r] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 32; ++kk)
+      st = __builtin_amdgcn_mfma_f32_32x32x2f32(Ks[buf][col][2 * kk + half], qf[kk], st, 0, 0, 0);
+    // ---- online softmax over this chunk's keys; lane holds keys (r&3) + 8(r>>2) + 4half of column `col`
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = c * KC + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool ok = key < p.Lk && (!p.causal || key <= qrow);
+      st[r] = ok ? st[r] : -INFINITY;
+      cmax = fmaxf(cmax, st[r]);
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    const float mnew = fmaxf(mrun, cmax);
+    const float msafe = mnew == -INFINITY ? 0.f : mnew;           // fully masked so far: keep everything at 0
+    const float alpha = expf(mrun - msafe);                       // exp(-inf) = 0 on the first chunk
+    float csum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - msafe); csum += st[r]; }
+    csum += __shfl_xor(csum, 32);
+    lrun = lrun * alpha + csum;
+    mrun = mnew;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
+    // ---- O^T (d x queries) += V^T (d x keys) . P^T (keys x queries); P^T register r IS the B fragment of the
+    // k-pair {key (r&3)+8(r>>2) [half 0], that key + 4 [half 1]}; the A fragment reads V in the same key order
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        ot[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[buf][key][32 * t + col], st[r], ot[t], 0, 0, 0);
+    }
+    if (c + 1 < nchunks) stash(buf ^ 1);
+    __syncthreads();
+  }
+  // ---- normalise and store O[query][d]: registers 4g..4g+3 of a tile are 4 consecutive d -> one float4 store
+  if (qok) {
+    const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * t + 8 * g + 4 * half;
+        *reinterpret_cast<float4*>(O + (long)qrow * p.old + d0) =
+            make_float4(ot[t][4 * g] * inv, ot[t][4 * g + 1] * inv, ot[t][4 * g + 2] * inv, ot[t][4 * g + 3] * inv);
+      }
+  }
+}
+
+}  // namespace
+
+// q, k, v, o: row matrices; element (b, row, h, c) lives at base + b*bs + row*ld + h*64 + c.
+extern "C" int ick_attention_fwd_d64(const float* q, int64_t qld, int64_t qbs, const float* k, int64_t kld, int64_t kbs,
+                                     const float* v, int64_t vld, int64_t vbs, float* o, int64_t old, int64_t obs,
+                                     int B, int H, int Lq, int Lk, int causal, float scale, void* stream) {
+  ICK_REQUIRE(q && k && v && o && B > 0 && H > 0 && Lq > 0 && Lk > 0, "ick_attention_fwd_d64: bad arguments");
+  ICK_REQUIRE((kld | vld | old | kbs | vbs | obs) % 4 == 0 && ick::aligned16(k) && ick::aligned16(v) && ick::aligned16(o),
+              "ick_attention_fwd_d64: K/V/O rows must be 16-byte aligned");
+  AP p{q, k, v, o, qld, kld, vld, old, qbs, kbs, vbs, obs, H, Lq, Lk, causal, scale};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int tiles = (Lq + 31) / 32;
+  if (tiles >= 4) {
+    ICK_LAUNCH((attn_fwd_kernel<4>), dim3(B * H, (tiles + 3) / 4), dim3(256), 0, st, p);
+  } else if (tiles >= 2) {
+    ICK_LAUNCH((attn_fwd_kernel<2>), dim3(B * H, (tiles + 1) / 2), dim3(128), 0, st, p);
+  } else {
+    ICK_LAUNCH((attn_fwd_kernel<1>), dim3(B * H, 1), dim3(64), 0, st, p);
+  }
+  return ick::launch_status("attention_fwd_d64");
+}

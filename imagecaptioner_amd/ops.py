@@ -199,6 +199,25 @@ def attention_fwd(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, koff: i
     return O, P
 
 
+def attention_fwd_fused(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, koff: int, kld: int, v: torch.Tensor,
+                        voff: int, vld: int, B: int, H: int, Lq: int, Lk: int, d: int, causal: bool = False,
+                        kv_batch_stride: Optional[int] = None) -> torch.Tensor:
+    """Forward-only attention with the score matrix kept on chip (csrc/attention.hip); same operand addressing as
+    attention_fwd.  Returns O [B*Lq][H*d].  Only d == 64 is built (every attention of the teacher has d = 64)."""
+    if d != 64:
+        return attention_fwd(q, qoff, qld, k, koff, kld, v, voff, vld, B, H, Lq, Lk, d, causal,
+                             kv_batch_stride=kv_batch_stride)[0]
+    E = H * d
+    O = empty(B * Lq, E, device=q.device)
+    fs = 4
+    kbs = Lk * kld if kv_batch_stride is None else kv_batch_stride
+    vbs = Lk * vld if kv_batch_stride is None else kv_batch_stride
+    check(_lib.lib().ick_attention_fwd_d64(q.data_ptr() + qoff * fs, qld, Lq * qld, k.data_ptr() + koff * fs, kld, kbs,
+                                           v.data_ptr() + voff * fs, vld, vbs, O.data_ptr(), E, Lq * E, B, H, Lq, Lk,
+                                           int(causal), 1.0 / math.sqrt(d), _st()), "ick_attention_fwd_d64")
+    return O
+
+
 def attention_bwd(dO: torch.Tensor, P: torch.Tensor, q, qoff, qld, k, koff, kld, v, voff, vld,
                   dq, dqoff, dqld, dk, dkoff, dkld, dv, dvoff, dvld, B, H, Lq, Lk, d, p_drop: float = 0.0, seed: int = 0):
     """Backward of attention_fwd; writes dQ/dK/dV into the given row matrices at the same packed offsets."""

@@ -74,8 +74,7 @@ def self_attention(x2, B, L, H, w_qkv, b_qkv, causal=False):
     """packed projection + attention core; x2 [(B*L)][E] -> O [(B*L)][E]"""
     E = x2.shape[1]
     qkv = ops.linear_fwd(x2, w_qkv, b_qkv)
-    O, _ = ops.attention_fwd(qkv, 0, 3 * E, qkv, E, 3 * E, qkv, 2 * E, 3 * E, B, H, L, L, E // H, causal)
-    return O
+    return ops.attention_fwd_fused(qkv, 0, 3 * E, qkv, E, 3 * E, qkv, 2 * E, 3 * E, B, H, L, L, E // H, causal)
 
 
 class VisionTransformerS16(nn.Module):
@@ -171,8 +170,8 @@ class CaptioningTeacher(nn.Module):
                                          lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, save=False)
             q = ops.linear_fwd(x2, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
             kv = ops.linear_fwd(mem2, ca.in_proj_weight[E:], ca.in_proj_bias[E:])      # [(Bm*L)][2E]
-            o, _ = ops.attention_fwd(q, 0, E, kv, 0, 2 * E, kv, E, 2 * E, B, H, T, L, E // H, False,
-                                     kv_batch_stride=None if Bm == B else 0)
+            o = ops.attention_fwd_fused(q, 0, E, kv, 0, 2 * E, kv, E, 2 * E, B, H, T, L, E // H, False,
+                                        kv_batch_stride=None if Bm == B else 0)
             x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, ca.out_proj.weight, ca.out_proj.bias, residual=x2),
                                          lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, save=False)
             h = ops.linear_fwd(x2, lyr.linear1.weight, lyr.linear1.bias, act=ACT_RELU)

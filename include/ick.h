@@ -73,6 +73,15 @@ typedef struct IckGemm {
 
 int ick_gemm_f32(const IckGemm* desc, void* stream);
 
+/* ------------------------------------------------------------------ fused attention forward (head dim 64)
+ * softmax(Q K^T * scale [causal]) V per (batch, head) without materialising the scores: timm ViT-S/16 self-attention
+ * (teacher_model.py:82), nn.TransformerDecoderLayer self/cross attention (teacher_model.py:60-67).  Element (b,row,h,c) of
+ * an operand lives at base + b*bs + row*ld + h*64 + c (packed in_proj outputs are addressed in place; kbs = vbs = 0 lets
+ * every batch entry attend to the same memory, the beam-search case). */
+int ick_attention_fwd_d64(const float* q, int64_t qld, int64_t qbs, const float* k, int64_t kld, int64_t kbs,
+                          const float* v, int64_t vld, int64_t vbs, float* o, int64_t old, int64_t obs,
+                          int B, int H, int Lq, int Lk, int causal, float scale, void* stream);
+
 /* ------------------------------------------------------------------ layout transforms
  * images arrive as the reference hands them over: (B,3,224,224) fp32 NCHW (train_student_kd.py:259). */
 int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stream);      /* -> (B,H,W,4), 4th channel 0 */
