@@ -28,6 +28,16 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMAGE = 28.4          # algorithmic, SURVEY.md §8(d): teacher 9.80 + student fwd+loss+bwd 18.61 (2 FLOP per MAC)
 PEAK_F32_MFMA_TF = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TF = 2516.0      # same guide: ~2.5 PF dense bf16 (v_mfma_f32_32x32x16_bf16 = 16x the fp32 MFMA rate)
+GFLOP_TEACHER, GFLOP_STUDENT = 9.80, 18.61
+
+
+def mfma_peak(precision: str):
+    """Roofline denominator for the step: the teacher always runs on the fp32 MFMA; the student's contractions run on
+    the fp32 MFMA ("f32"), on the bf16 MFMA ("bf16") or as 3 bf16 MFMAs per product ("bf16x3").  The blended peak
+    is total FLOPs / (time of each part at its own MFMA peak)."""
+    ps = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 3}[precision]
+    return GFLOP_PER_IMAGE / (GFLOP_TEACHER / PEAK_F32_MFMA_TF + GFLOP_STUDENT / ps)
 BATCH = 64
 VOCAB, T1 = 5000, 16
 
@@ -89,6 +99,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3"],
+                    help="student/projector GEMM arithmetic (teacher stays fp32 as in the reference); f32 = parity regime")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +121,7 @@ def main():
 
     student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev)    # identical init on every rank
     trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
-                        use_graph=not args.no_graph)
+                        use_graph=not args.no_graph, precision=args.precision)
     images, caps = synthetic_batch(args.batch, VOCAB, T1, seed=1234, rank=rank)     # rank-specific shard of the global batch
     log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
     log("models built; first step (hipGraph capture) ...")
@@ -144,20 +156,24 @@ def main():
         ips = world * args.batch * args.steps / dt
         step_ms_dev = dev_ms / args.steps
         achieved = GFLOP_PER_IMAGE * args.batch / step_ms_dev            # GFLOP / ms = TFLOP/s, this rank's GPU
+        peak = mfma_peak(args.precision)
+        dtype = {"f32": "f32", "bf16": "bf16 student (fp32 accumulate, fp32 master weights) + f32 teacher",
+                 "bf16x3": "split-bf16x3 student + f32 teacher"}[args.precision]
         out = {
             "metric": "images/sec KD train step (teacher+student fwd + KD loss + bwd)", "value": round(ips, 2),
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": "cfg3 full KD step: vit_small_patch16_224 teacher (embed 512/8 heads/4 layers) + "
                                    "ResNet50-LSTM student (256/512/2-layer, refinement on), alpha=0.7 beta=0.2 gamma=0.1 T=4, "
                                    "V=5000, T=15, 224x224, clip 1.0 + AdamW every step",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "final_loss": round(loss["total_loss"], 5)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA_TF, 4), "traffic": measured_traffic(args.batch),
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": measured_traffic(args.batch),
                          "note": "whole step: 28.4 algorithmic GFLOP/image (SURVEY 8d) x batch / device time per step "
-                                 "(HIP events on the launch stream); denominator = fp32 MFMA peak (exact-fp32 path)"},
+                                 "(HIP events on the launch stream); denominator = fp32 MFMA peak for the exact-fp32 path, else the "
+                                 "FLOP-weighted blend of the fp32 (teacher) and bf16 (student) MFMA peaks"},
         }
         if world == 1 and not args.no_cpu_baseline:
             del trainer, student, teacher, projectors

@@ -1,70 +1,94 @@
-// igemm_f32.hip — fp32 implicit-GEMM family on the CDNA4 matrix cores (gfx950).
+// igemm_bf16.hip — the implicit-GEMM family of igemm_f32.hip on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16,
+// 16x the fp32 MFMA rate), for the mixed-precision (AMP) regime the reference trains in
+// (torch.cuda.amp.autocast + GradScaler, src/train_student_kd.py:263-290).
 //
-//   C[z][m][n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) + residual[m][n]
+//   C[z][m][n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) + residual[m][n]        (fp32 in HBM, fp32 accumulate)
 //
-// One LDS-tiled kernel template built on v_mfma_f32_32x32x2_f32 (exact fp32: the result is
-// a k-ordered fmaf chain, so parity with the reference's fp32 CPU path holds to ~1e-6) serves
-// every dense contraction of the KD step: Linear fwd/bwd, batched attention products, and the
-// ResNet-50 convolutions (fwd / dgrad / wgrad) as implicit GEMM over NHWC activations.
+// Operands stay fp32 in HBM (same descriptors, same layouts, same epilogues as the fp32 family); they are rounded
+// to bf16 on the way into LDS, so one step can run in either precision without touching the host code.
+//   TERMS == 1 : a ~ bf16(a)                    one MFMA per k-step         (autocast semantics, ~3 significant digits)
+//   TERMS == 3 : a = hi + lo, both bf16          hi*hi + hi*lo + lo*hi       (~16 mantissa bits per operand: within
+//                                                                              ~1e-5 relative of the exact fp32 product)
 //
-// Tiling (64-wide wavefronts): 256 threads = 4 waves in a 2x2 grid; block tile BMxBNx16;
-// each wave owns (BM/2)x(BN/2) = TMxTN MFMA tiles of 32x32 (16 accumulator VGPRs each).
-// Operand tiles live in LDS k-major, As[k][m] / Bs[k][n], so the MFMA fragment read
-// (lane l: A[m = l&31][k = l>>5]) is one conflict-free ds_read_b32 per tile per k-pair.
-//   * a source that is contiguous along K (row-major activations, conv im2col over NHWC
-//     channels, [N][K] weights) is fetched as float4 along k and TRANSPOSED on the LDS write
-//     (4 x ds_write_b32; row pitch = BX+2 makes the 32-lane write group conflict-free);
-//   * a source that is contiguous along M/N ([K][N] weights for dgrad, dY^T for wgrad) is
-//     fetched as float4 along x and stored with one ds_write_b128 (row pitch BX+4).
-// Global->LDS is software pipelined through registers (issue tile t+1's loads, run tile t's
-// MFMAs, then write t+1 into the other LDS buffer): one barrier per k-tile.
+// Tiling: 256 threads = 4 waves (2x2), block tile BM x BN x 32, wave tile (BM/2)x(BN/2) as 32x32 MFMA tiles.
+// Two LDS images, chosen by how the SOURCE is contiguous (coalesced 16-byte global loads either way):
+//   * k-contiguous source (activations [M][K], [N][K] weights, im2col over NHWC channels): image [x][k], row pitch
+//     80 B; written with ds_write_b64 (4 k), fragment = one ds_read_b128 (8 k at row = lane&31, k-half = lane>>5);
+//     pitch 80 B = 5 sixteen-byte slots makes the four 16-lane groups of ds_read_b128 conflict-free;
+//   * x-contiguous source ([K][N] weights, dY^T, wgrad gathers): image [k][x], row pitch 2*BX+64 B, written with
+//     ds_write_b64 (4 x); the fragment is TRANSPOSED ON THE READ by two ds_read_b64_tr_b16 (4 k-rows x 16 columns per
+//     16-lane group): no register transpose, no scattered 2-byte writes; pitch mod 256 B = 64 B makes the reads
+//     conflict-free per 32-lane half.
+// Global->LDS is register-staged (the fp32->bf16 rounding has to happen in flight): tile t+1's loads are issued
+// before tile t's MFMAs and written to the other LDS buffer after them; one barrier per k-tile.
 #include "igemm_params.h"
 #include <type_traits>
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 16;
-constexpr int NT = 256;
-#ifndef ICK_STASH_AT
-#define ICK_STASH_AT 10
-#endif
-constexpr int STASH_AT = ICK_STASH_AT;   // k offset inside a tile after which the next tile is written to LDS
-
 using namespace ickg;
 
-template <int OP, int BM, int BN>
-__global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
-  constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
-  constexpr int BMP = BM + (AK ? 2 : 4), BNP = BN + (BKc ? 2 : 4);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  // k-contiguous fetch: 4 threads per row, 64 rows per pass; x-contiguous: BX/4 threads per k-row
-  constexpr int PA = AK ? BM / 64 : (BK * BM) / 1024;
-  constexpr int PB = BKc ? BN / 64 : (BK * BN) / 1024;
-  constexpr int A_TPK = BM / 4, B_TPK = BN / 4;        // threads per k-row (x-contiguous)
-  constexpr int A_KR = NT / A_TPK, B_KR = NT / B_TPK;  // k-rows per pass   (x-contiguous)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
 
-  __shared__ __attribute__((aligned(16))) float As[2][BK][BMP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BNP];
+constexpr int BK = 32;
+constexpr int NT = 256;
+constexpr int KCP = BK + 8;   // row pitch (elements) of a k-contiguous image: 80 bytes
+
+template <bool KC, int BX>
+constexpr int img_elems() { return KC ? BX * KCP : BK * (BX + 32); }
+
+// 4 fp32 -> 4 bf16 (round to nearest even) stored as 8 bytes; with SPLIT also the bf16 of the rounding residual
+template <bool SPLIT>
+__device__ __forceinline__ void store4(u16* dst, int lo_off, float4 v) {
+  const f32x4 x = {v.x, v.y, v.z, v.w};
+  const bf16x4 h = __builtin_convertvector(x, bf16x4);
+  *reinterpret_cast<bf16x4*>(dst) = h;
+  if constexpr (SPLIT) {
+    const f32x4 r = x - __builtin_convertvector(h, f32x4);
+    *reinterpret_cast<bf16x4*>(dst + lo_off) = __builtin_convertvector(r, bf16x4);
+  }
+}
+
+__device__ __forceinline__ bf16x8 tr_read8(const u16* p, int row_pitch) {
+  typedef __attribute__((address_space(3))) s16x4* lds_p;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * row_pitch));
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int OP, int BM, int BN, int TERMS>
+__global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
+  constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
+  constexpr bool SPLIT = TERMS == 3;
+  constexpr int IMGS = SPLIT ? 2 : 1;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int PA = BM / 32, PB = BN / 32;             // 16-byte fetches per thread per k-tile
+  constexpr int A_TPK = BM / 4, B_TPK = BN / 4;         // threads per k-row (x-contiguous fetch)
+  constexpr int A_KR = NT / A_TPK, B_KR = NT / B_TPK;   // k-rows per pass   (x-contiguous fetch)
+  constexpr int A_XP = BM + 32, B_XP = BN + 32;         // row pitch of the [k][x] images
+  constexpr int A_SZ = img_elems<AK, BM>(), B_SZ = img_elems<BKc, BN>();
+  constexpr int BUF = IMGS * (A_SZ + B_SZ);
+
+  __shared__ __attribute__((aligned(16))) u16 lds[2 * BUF];   // [buffer][A hi, A lo, B hi, B lo]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  // XCD-aware tile order: the dispatcher deals workgroup ids round-robin over the 8 XCDs (each with its own L2);
-  // remap so that every XCD walks a CONTIGUOUS range of tiles (row-major over N then M): the A row panel
-  // (activations, the large operand) is then fetched into one L2 instead of up to eight (bijective for any grid).
+  // XCD-aware tile order (see igemm_f32.hip): every XCD walks a contiguous range of tiles
   const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // batch / split-K decomposition of blockIdx.z
   int z = blockIdx.z, split = 0;
   if (p.splitk > 1) { split = z; z = 0; }
-  // stride-2 dgrad: blockIdx.z = parity class (py,px) of the input pixel; only the taps r = r0, r0+2, .. with
-  // (iy + pad - r) even can reach it, so each class is a dense GEMM over its own nr*ns taps (no multiplies by zero)
   int py = 0, px = 0, r0 = 0, s0 = 0, ns = 1, kcls = 0;
-  if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
+  if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // parity class of the input pixel (see igemm_f32.hip)
     py = z >> 1; px = z & 1; z = 0;
     r0 = (py + p.pad) & 1; s0 = (px + p.pad) & 1;
     const int nr = p.R > r0 ? (p.R - r0 + 1) / 2 : 0;
@@ -80,13 +104,12 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
   const int nkt = (kend - kbeg + BK - 1) / BK;
 
   // ---------------------------------------------------------------- per-thread fetch state
-  // A side
   const float* a_ptr[PA]; bool a_ok[PA]; int a_y[PA], a_x[PA];
-  const int a_k4 = (tid & 3) * 4;  // k offset inside the tile (k-contiguous fetch)
+  const int a_k4 = (tid & 7) * 4;   // k offset inside the tile (k-contiguous fetch: 8 threads x 16 B = one 128-B row)
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
     if constexpr (AK) {
-      const int m = m0 + i * 64 + (tid >> 2);
+      const int m = m0 + i * 32 + (tid >> 3);
       a_ok[i] = m < p.M;
       if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
         a_ptr[i] = Ag + (long)m * p.lda + a_k4; a_y[i] = a_x[i] = 0;
@@ -95,36 +118,35 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
         const int oy = r / p.Wo, ox = r - oy * p.Wo;
         a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad;
         a_ptr[i] = Ag + (long)b * p.H * p.W * p.Cin;
-      } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {  // rows = input pixels of this parity class
+      } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
         const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int r = m - b * hw;
         const int iy = 2 * (r / w2) + py, ix = 2 * (r % w2) + px;
         a_y[i] = iy + p.pad; a_x[i] = ix + p.pad;
         a_ptr[i] = Ag + (long)b * p.Ho * p.Wo * p.Cout;
-      } else {  // CONV_DGRAD: rows are input pixels, gather from dY
+      } else {  // CONV_DGRAD
         const int hw = p.H * p.W; const int b = m / hw; const int r = m - b * hw;
         const int iy = r / p.W, ix = r - iy * p.W;
         a_y[i] = iy + p.pad; a_x[i] = ix + p.pad;
         a_ptr[i] = Ag + (long)b * p.Ho * p.Wo * p.Cout;
       }
-    } else {  // x-contiguous: A stored [K][M]
+    } else {  // A stored [K][M]
       const int m = m0 + (tid % A_TPK) * 4;
       a_ok[i] = m < p.M;
       a_ptr[i] = Ag + m; a_y[i] = i * A_KR + tid / A_TPK; a_x[i] = 0;
     }
   }
-  // B side
-  const float* b_ptr[PB]; bool b_ok[PB]; int b_y[PB], b_x[PB];
+  const float* b_ptr[PB]; bool b_ok[PB]; int b_y[PB];
   int b_r = 0, b_s = 0;
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     if constexpr (BKc) {
-      const int n = n0 + i * 64 + (tid >> 2);
+      const int n = n0 + i * 32 + (tid >> 3);
       b_ok[i] = n < p.N;
-      b_ptr[i] = Bg + (long)n * p.ldb + a_k4; b_y[i] = b_x[i] = 0;
+      b_ptr[i] = Bg + (long)n * p.ldb + a_k4; b_y[i] = 0;
     } else {
       const int n = n0 + (tid % B_TPK) * 4;
       b_ok[i] = n < p.N;
-      b_y[i] = i * B_KR + tid / B_TPK; b_x[i] = 0;
+      b_y[i] = i * B_KR + tid / B_TPK;
       if constexpr (OP == ICK_OP_CONV_WGRAD) {
         const int tap = n / p.Cin; const int ci = n - tap * p.Cin;
         b_r = tap / p.S; b_s = tap - b_r * p.S;
@@ -136,12 +158,11 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
   }
 
   float4 ra[PA], rb[PB];
-  unsigned amask = 0, bmask = 0;   // bit i: fetch i of the tile in flight is in range
+  unsigned amask = 0, bmask = 0;
 
   auto fetch = [&](int kt) {
     const int k0 = kbeg + kt * BK;
     amask = 0; bmask = 0;
-    // ---- A
     if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
@@ -185,7 +206,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
       const int r = r0 + 2 * (q / ns), s = s0 + 2 * (q % ns);
 #pragma unroll
       for (int i = 0; i < PA; ++i) {
-        const int ty = a_y[i] - r, tx = a_x[i] - s;        // even by construction
+        const int ty = a_y[i] - r, tx = a_x[i] - s;
         const int oy = ty >> 1, ox = tx >> 1;
         const bool ok = a_ok[i] && ty >= 0 && tx >= 0 && oy < p.Ho && ox < p.Wo && (k0 + a_k4 < kend);
         amask |= ok ? (1u << i) : 0u;
@@ -200,7 +221,6 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
         ra[i] = ldg4u(a_ptr[i] + (long)k * p.lda, ok, Ag);
       }
     }
-    // ---- B
     if constexpr (BKc) {
 #pragma unroll
       for (int i = 0; i < PB; ++i) {
@@ -249,19 +269,19 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
     }
   };
 
-  // write the fetched tile `kt` into LDS buffer `buf` (zeroing what was out of range)
+  // round the fetched tile `kt` to bf16 and write it into LDS buffer `buf` (zeroing what was out of range)
   auto stash = [&](int buf, int kt) {
     const int kq = kbeg + kt * BK + a_k4;
+    u16* Ab = lds + buf * BUF;
+    u16* Bb = Ab + IMGS * A_SZ;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       float4 v = keep_if(ra[i], (amask >> i) & 1u);
       if constexpr (AK) {
         if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) v = ktail(v, kq, kend);
-        const int x = i * 64 + (tid >> 2);
-        As[buf][a_k4 + 0][x] = v.x; As[buf][a_k4 + 1][x] = v.y;
-        As[buf][a_k4 + 2][x] = v.z; As[buf][a_k4 + 3][x] = v.w;
+        store4<SPLIT>(Ab + (i * 32 + (tid >> 3)) * KCP + a_k4, A_SZ, v);
       } else {
-        *reinterpret_cast<float4*>(&As[buf][i * A_KR + tid / A_TPK][(tid % A_TPK) * 4]) = v;
+        store4<SPLIT>(Ab + (i * A_KR + tid / A_TPK) * A_XP + (tid % A_TPK) * 4, A_SZ, v);
       }
     }
 #pragma unroll
@@ -269,12 +289,30 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
       float4 v = keep_if(rb[i], (bmask >> i) & 1u);
       if constexpr (BKc) {
         v = ktail(v, kq, kend);
-        const int x = i * 64 + (tid >> 2);
-        Bs[buf][a_k4 + 0][x] = v.x; Bs[buf][a_k4 + 1][x] = v.y;
-        Bs[buf][a_k4 + 2][x] = v.z; Bs[buf][a_k4 + 3][x] = v.w;
+        store4<SPLIT>(Bb + (i * 32 + (tid >> 3)) * KCP + a_k4, B_SZ, v);
       } else {
-        *reinterpret_cast<float4*>(&Bs[buf][i * B_KR + tid / B_TPK][(tid % B_TPK) * 4]) = v;
+        store4<SPLIT>(Bb + (i * B_KR + tid / B_TPK) * B_XP + (tid % B_TPK) * 4, B_SZ, v);
       }
+    }
+  };
+
+  // MFMA operand fragment of k-step s (16 k): lane l holds X[row l&31][k = 8*(l>>5) + 0..7]
+  const int frow = lane & 31, fk = lane >> 5;
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;   // transposed read: group, block row, 4-column piece
+  auto frag_a = [&](int buf, int img, int s, int i) -> bf16x8 {
+    const u16* base = lds + buf * BUF + img * A_SZ;
+    if constexpr (AK) {
+      return *reinterpret_cast<const bf16x8*>(base + (wm * WM + i * 32 + frow) * KCP + s * 16 + fk * 8);
+    } else {
+      return tr_read8(base + (s * 16 + (tg >> 1) * 8 + tq) * A_XP + wm * WM + i * 32 + (tg & 1) * 16 + tp * 4, A_XP);
+    }
+  };
+  auto frag_b = [&](int buf, int img, int s, int j) -> bf16x8 {
+    const u16* base = lds + buf * BUF + IMGS * A_SZ + img * B_SZ;
+    if constexpr (BKc) {
+      return *reinterpret_cast<const bf16x8*>(base + (wn * WN + j * 32 + frow) * KCP + s * 16 + fk * 8);
+    } else {
+      return tr_read8(base + (s * 16 + (tg >> 1) * 8 + tq) * B_XP + wn * WN + j * 32 + (tg & 1) * 16 + tp * 4, B_XP);
     }
   };
 
@@ -292,45 +330,37 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
   }
   __syncthreads();
 
-  const int fa = wm * WM + (lane & 31), fb = wn * WN + (lane & 31), fk = lane >> 5;
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) fetch(kt + 1);
-    // fragment registers are double-buffered by hand: the ds_reads of k-pair kk+2 are issued BEFORE the MFMAs of
-    // k-pair kk, so their LDS latency hides behind 4 x 64 MFMA cycles even with a single wave on the SIMD
-    float av[2][TM], bv[2][TN];
+    bf16x8 av[2][IMGS][TM], bv[2][IMGS][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) av[0][i] = As[buf][fk][fa + i * 32];
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bv[0][j] = Bs[buf][fk][fb + j * 32];
+      for (int g = 0; g < IMGS; ++g) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const int cur = (kk >> 1) & 1, nxt = cur ^ 1;
-      if (kk + 2 < BK) {
+        for (int i = 0; i < TM; ++i) av[s][g][i] = frag_a(buf, g, s, i);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[nxt][i] = As[buf][kk + 2 + fk][fa + i * 32];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bv[nxt][j] = Bs[buf][kk + 2 + fk][fb + j * 32];
+        for (int j = 0; j < TN; ++j) bv[s][g][j] = frag_b(buf, g, s, j);
       }
-      // the LDS write of tile kt+1 (other buffer: nobody reads it during tile kt) goes in the shadow of the
-      // second half of this tile's MFMAs instead of between the last MFMA and the barrier
-      if (kk == STASH_AT && kt + 1 < nkt) stash(buf ^ 1, kt + 1);
-      // scheduling fence: keeps "next fragments' LDS reads" ahead of this k-pair's MFMAs (hipcc otherwise sinks the
-      // reads behind the MFMAs and waits lgkmcnt(0) in front of every group)
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (SPLIT) {   // small terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][1][i], bv[s][0][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][0][i], bv[s][1][j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][0][i], bv[s][0][j], acc[i][j], 0, 0, 0);
+        }
+    if (kt + 1 < nkt) stash(buf ^ 1, kt + 1);
     __syncthreads();
   }
 
-  // ---------------------------------------------------------------- epilogue
+  // ---------------------------------------------------------------- epilogue (identical to the fp32 family)
   // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // Interior tiles (the vast majority) take a check-free path; flags are wave-uniform scalars.
   float* __restrict__ Cg = p.C + coff;
   const float* __restrict__ Rg = (p.residual && split == 0) ? p.residual + coff : nullptr;
   const float* __restrict__ biasp = (p.bias && split == 0) ? p.bias : nullptr;
@@ -356,7 +386,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
             ssum += v; ssq += v * v;
             v = act_fn(v + bias, act);
             long mr = m;
-            if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // class row -> pixel row of the full-resolution dX
+            if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
               const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
               mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
             }
@@ -368,7 +398,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
           }
         }
       }
-      if (p.stat_sum) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
+      if (p.stat_sum) {
         ssum += __shfl_xor(ssum, 32);
         ssq += __shfl_xor(ssq, 32);
         if (lane < 32 && nok) { atomicAdd(p.stat_sum + n, (double)ssum); atomicAdd(p.stat_sq + n, (double)ssq); }
@@ -379,87 +409,100 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
   else epilogue(std::false_type{});
 }
 
-template <int OP, int BM, int BN>
+template <int OP, int BM, int BN, int TERMS>
 int launch(const P& p0, int nz, hipStream_t st) {
   P p = p0;
   p.tiles_n = (p.N + BN - 1) / BN;
   dim3 grid(p.tiles_n * ((p.M + BM - 1) / BM), 1, nz);
-  ICK_LAUNCH((igemm_f32_kernel<OP, BM, BN>), grid, dim3(NT), 0, st, p);
-  return ick::launch_status("igemm_f32");
+  ICK_LAUNCH((igemm_bf16_kernel<OP, BM, BN, TERMS>), grid, dim3(NT), 0, st, p);
+  return ick::launch_status("igemm_bf16");
 }
 
-// Tile choice.  fp32 MFMA is slow enough (64 cycles per 32x32x2) that all four tile shapes keep the matrix pipe
-// fed; what separates them on the step's shapes is WAVE QUANTISATION over the 256 CUs: a grid of T workgroups
-// with R resident per CU finishes in ceil(T / 256 / R) * R "slots" of unequal value.  Cost model: every
-// workgroup costs its MFMA work (tile area) plus a fixed per-k-tile overhead that weighs more on small tiles;
-// the grid costs max-per-CU work.  tile: 0 = model, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128.
-template <int OP>
+// Tile choice: the same wave-quantisation model as the fp32 family (max work per CU), with a flatter efficiency
+// ladder: at bf16 MFMA rates every tile shape is fed by the fp32 operand stream from L2, not by the matrix pipe.
+// The split (TERMS == 3) 128x128 tile would need 80 KB of LDS per workgroup; it is not built.
+template <int OP, int TERMS>
 int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
-  if (tile == 0) {
+  constexpr bool BIG = TERMS == 1;
+  if (tile == 0 || (!BIG && tile == 1)) {
     static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
-    static const double eff[4] = {1.00, 0.80, 0.90, 0.90};   // relative MFMA efficiency of the tile shape
+    static const double eff[4] = {1.00, 0.70, 0.85, 0.85};
     double best = 1e300;
-    for (int t = 0; t < 4; ++t) {
+    tile = 2;
+    for (int t = BIG ? 0 : 1; t < 4; ++t) {
       const long blocks = (long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * nz;
-      const long per_cu = (blocks + 255) / 256;               // workgroups the busiest CU executes
+      const long per_cu = (blocks + 255) / 256;
       const double cost = (double)per_cu * bm[t] * bn[t] / eff[t];
       if (cost < best * 0.999) { best = cost; tile = t + 1; }
     }
   }
   switch (tile) {
-    case 2: return launch<OP, 64, 64>(p, nz, st);
-    case 3: return launch<OP, 128, 64>(p, nz, st);
-    case 4: return launch<OP, 64, 128>(p, nz, st);
-    default: return launch<OP, 128, 128>(p, nz, st);
+    case 2: return launch<OP, 64, 64, TERMS>(p, nz, st);
+    case 3: return launch<OP, 128, 64, TERMS>(p, nz, st);
+    case 4: return launch<OP, 64, 128, TERMS>(p, nz, st);
+    default:
+      if constexpr (BIG) return launch<OP, 128, 128, TERMS>(p, nz, st);
+      else return launch<OP, 128, 64, TERMS>(p, nz, st);
+  }
+}
+
+template <int TERMS>
+int run(const IckGemm* d, const P& p, int nz, hipStream_t st) {
+  switch (d->op) {
+    case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
+    case ICK_OP_NN: return dispatch_tile<ICK_OP_NN, TERMS>(p, nz, st, d->tile);
+    case ICK_OP_TN: return dispatch_tile<ICK_OP_TN, TERMS>(p, nz, st, d->tile);
+    case ICK_OP_CONV_FWD: return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
+    case ICK_OP_CONV_FWD_C4: return dispatch_tile<ICK_OP_CONV_FWD_C4, TERMS>(p, nz, st, d->tile);
+    case ICK_OP_CONV_DGRAD: return dispatch_tile<ICK_OP_CONV_DGRAD, TERMS>(p, nz, st, d->tile);
+    case ICK_OP_CONV_DGRAD_S2: return dispatch_tile<ICK_OP_CONV_DGRAD_S2, TERMS>(p, 4, st, d->tile);
+    case ICK_OP_CONV_WGRAD: return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS>(p, nz, st, d->tile);
+    default: return ick::fail(-1, "ick_gemm_bf16: unknown op %d", d->op);
   }
 }
 
 }  // namespace
 
-extern "C" int ick_gemm_f32(const IckGemm* d, void* stream) {
+extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
+  ICK_REQUIRE(terms == 1 || terms == 3, "ick_gemm_bf16: terms must be 1 (bf16) or 3 (split bf16), got %d", terms);
   P p; int nz = 1;
-  if (int rc = prepare(d, BK, p, nz, "ick_gemm_f32")) return rc;
+  if (int rc = prepare(d, BK, p, nz, "ick_gemm_bf16")) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d->op) {
-    case ICK_OP_NT:
-      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "NT: lda, ldb must be multiples of 4 (rows readable up to roundup4(K))");
-      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "NT: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_NT>(p, nz, st, d->tile);
-    case ICK_OP_NN:
-      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "NN: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
-      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "NN: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_NN>(p, nz, st, d->tile);
-    case ICK_OP_TN:
-      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "TN: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
-      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "TN: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_TN>(p, nz, st, d->tile);
+    case ICK_OP_NT: case ICK_OP_NN: case ICK_OP_TN:
+      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "ick_gemm_bf16: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
+      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "ick_gemm_bf16: batch strides must be multiples of 4");
+      break;
     case ICK_OP_CONV_FWD:
-      ICK_REQUIRE(p.Cin % BK == 0, "CONV_FWD: Cin=%d must be a multiple of %d", p.Cin, BK);
       ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * p.Cin && p.ldb == p.K,
                   "CONV_FWD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_FWD>(p, nz, st, d->tile);
+      if (p.Cin % BK != 0) return ick_gemm_f32(d, stream);   // a k-tile must not straddle two taps: exact-fp32 kernel (BK 16)
+      break;
     case ICK_OP_CONV_FWD_C4:
       ICK_REQUIRE(p.Cin == 4, "CONV_FWD_C4: Cin must be 4");
       ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * 4 && p.ldb == p.K,
                   "CONV_FWD_C4: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_FWD_C4>(p, nz, st, d->tile);
+      break;
     case ICK_OP_CONV_DGRAD:
-      ICK_REQUIRE(p.Cout % BK == 0 && p.Cin % 4 == 0, "CONV_DGRAD: Cout %% 16 and Cin %% 4 required");
+      ICK_REQUIRE(p.Cin % 4 == 0, "CONV_DGRAD: Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Nb * p.H * p.W && p.N == p.Cin && p.K == p.R * p.S * p.Cout,
                   "CONV_DGRAD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_DGRAD>(p, nz, st, d->tile);
+      if (p.Cout % BK != 0) return ick_gemm_f32(d, stream);
+      break;
     case ICK_OP_CONV_DGRAD_S2:
       ICK_REQUIRE(p.stride == 2 && p.H % 2 == 0 && p.W % 2 == 0, "CONV_DGRAD_S2: stride 2 and even H, W required");
-      ICK_REQUIRE(p.Cout % BK == 0 && p.Cin % 4 == 0, "CONV_DGRAD_S2: Cout %% 16 and Cin %% 4 required");
+      ICK_REQUIRE(p.Cin % 4 == 0, "CONV_DGRAD_S2: Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Nb * (p.H / 2) * (p.W / 2) && p.N == p.Cin && p.K == p.R * p.S * p.Cout && nz == 1 &&
                   p.splitk == 1, "CONV_DGRAD_S2: M must be the rows of ONE parity class; no batching / split-K");
-      return dispatch_tile<ICK_OP_CONV_DGRAD_S2>(p, 4, st, d->tile);
+      if (p.Cout % BK != 0) return ick_gemm_f32(d, stream);
+      break;
     case ICK_OP_CONV_WGRAD:
       ICK_REQUIRE(p.Cout % 4 == 0 && p.Cin % 4 == 0, "CONV_WGRAD: Cout %% 4 and Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Cout && p.N == p.R * p.S * p.Cin && p.K == p.Nb * p.Ho * p.Wo && p.lda == p.Cout,
                   "CONV_WGRAD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_WGRAD>(p, nz, st, d->tile);
+      break;
     default:
-      return ick::fail(-1, "ick_gemm_f32: unknown op %d", d->op);
+      return ick::fail(-1, "ick_gemm_bf16: unknown op %d", d->op);
   }
+  return terms == 3 ? run<3>(d, p, nz, st) : run<1>(d, p, nz, st);
 }

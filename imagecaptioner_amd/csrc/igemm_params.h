@@ -1,0 +1,90 @@
+// igemm_params.h — kernel parameter block and guarded-fetch helpers shared by the implicit-GEMM kernel families
+// (igemm_f32.hip: exact fp32 MFMA; igemm_bf16.hip: bf16 / split-bf16 MFMA over the same fp32 operands in HBM).
+#pragma once
+#include "ick_common.h"
+
+namespace ickg {
+
+struct P {  // kernel parameters (by value)
+  const float* A; const float* B; float* C;
+  const float* bias; const float* residual; double* stat_sum; double* stat_sq;
+  int M, N, K;
+  long lda, ldb, ldc, ldr;
+  int batch_inner;
+  long sAo, sAi, sBo, sBi, sCo, sCi;
+  int splitk, kps, accumulate, act, tiles_n;
+  float alpha;
+  int Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+};
+
+// which fetch pattern each op uses for its A and B operands
+__host__ __device__ constexpr bool a_kcontig(int op) { return op != ICK_OP_TN && op != ICK_OP_CONV_WGRAD; }
+__host__ __device__ constexpr bool is_dgrad(int op) { return op == ICK_OP_CONV_DGRAD || op == ICK_OP_CONV_DGRAD_S2; }
+__host__ __device__ constexpr bool b_kcontig(int op) {
+  return op == ICK_OP_NT || op == ICK_OP_CONV_FWD || op == ICK_OP_CONV_FWD_C4;
+}
+
+// Branch-free guarded fetch: a lane whose element is out of range reads a valid dummy address and its value is
+// zeroed where it is CONSUMED (the LDS stash), so the 16-byte loads of tile t+1 stay in flight across tile t's MFMAs.
+// (A branchy `ok ? load : 0` makes hipcc emit s_waitcnt vmcnt(0) right behind the loads: load->compute serialised.)
+__device__ __forceinline__ float4 ldg4u(const float* p, bool ok, const float* safe) {
+  return *reinterpret_cast<const float4*>(ok ? p : safe);
+}
+__device__ __forceinline__ float4 keep_if(float4 v, bool ok) {
+  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
+// k-contiguous rows whose valid range ends at kend (any kend: the row pitch is a multiple of 4, so the 16-byte load
+// stays inside the row): zero the components at k+1..k+3 that lie past kend
+__device__ __forceinline__ float4 ktail(float4 v, int k, int kend) {
+  if (k + 3 >= kend) {
+    if (k + 1 >= kend) v.y = 0.f;
+    if (k + 2 >= kend) v.z = 0.f;
+    v.w = 0.f;
+  }
+  return v;
+}
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+  if (act == ICK_ACT_RELU) return v > 0.f ? v : 0.f;
+  if (act == ICK_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  if (act == ICK_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+// Copies the descriptor into the kernel parameter block and derives the split-K partition for a k-tile depth of `bk`.
+// Returns 0 or a negative status with ick_last_error() set; nz = grid.z.
+inline int prepare(const IckGemm* d, int bk, P& p, int& nz, const char* who) {
+  ICK_REQUIRE(d != nullptr, "%s: null descriptor", who);
+  ICK_REQUIRE(d->A && d->B && d->C, "%s: null operand pointer", who);
+  ICK_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "%s: empty problem M=%d N=%d K=%d", who, d->M, d->N, d->K);
+  ICK_REQUIRE(ick::aligned16(d->A) && ick::aligned16(d->B), "%s: A/B must be 16-byte aligned", who);
+  p = P{};
+  p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
+  p.stat_sum = d->stat_sum; p.stat_sq = d->stat_sq;
+  p.M = d->M; p.N = d->N; p.K = d->K;
+  p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
+  p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;
+  const int bo = d->batch_outer > 0 ? d->batch_outer : 1;
+  p.sAo = d->sAo; p.sAi = d->sAi; p.sBo = d->sBo; p.sBi = d->sBi; p.sCo = d->sCo; p.sCi = d->sCi;
+  p.splitk = d->splitk > 1 ? d->splitk : 1;
+  p.accumulate = d->accumulate; p.act = d->act; p.alpha = d->alpha;
+  p.Nb = d->Nb; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+  p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
+  nz = bo * p.batch_inner;
+  ICK_REQUIRE((d->stat_sum == nullptr) == (d->stat_sq == nullptr), "%s: stat_sum and stat_sq go together", who);
+  if (p.splitk > 1) {
+    ICK_REQUIRE(nz == 1, "%s: split-K and batching are exclusive", who);
+    ICK_REQUIRE(p.act == ICK_ACT_NONE && !p.stat_sum, "%s: split-K cannot apply an activation or statistics", who);
+    const int tiles = (p.K + bk - 1) / bk;
+    const int per = (tiles + p.splitk - 1) / p.splitk;
+    p.kps = per * bk;
+    p.splitk = (tiles + per - 1) / per;
+    nz = p.splitk;
+  } else {
+    p.kps = p.K;
+  }
+  ICK_REQUIRE(nz <= 65535, "%s: grid.z %d too large", who, nz);
+  return 0;
+}
+
+}  // namespace ickg

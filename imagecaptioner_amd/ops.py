@@ -61,6 +61,38 @@ def _load_tuned():
 
 _TUNED = _load_tuned()
 
+# Arithmetic of every dense contraction (Linear / attention products / convolutions): "f32" = exact fp32 MFMA (the
+# parity regime), "bf16" = bf16 MFMA with fp32 accumulation (the reference's autocast regime, train_student_kd.py:263),
+# "bf16x3" = split-bf16 (hi*hi + hi*lo + lo*hi, ~1e-5 of fp32).  Operands stay fp32 in HBM in all three.
+_PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 3}
+_PREC = ["f32"]
+
+
+def set_gemm_precision(name: str) -> None:
+    if name not in _PRECISIONS:
+        raise ValueError(f"unknown GEMM precision {name!r}; expected one of {sorted(_PRECISIONS)}")
+    _PREC[0] = name
+
+
+def gemm_precision() -> str:
+    return _PREC[0]
+
+
+class precision:
+    """with ops.precision("bf16"): ...  — scoped set_gemm_precision."""
+
+    def __init__(self, name: str):
+        self.name, self.prev = name, None
+
+    def __enter__(self):
+        self.prev = _PREC[0]
+        set_gemm_precision(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _PREC[0] = self.prev
+        return False
+
 
 def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *,
              bias: Optional[int] = None, residual: Optional[int] = None, ldr: int = 0, act: int = ACT_NONE,
@@ -79,6 +111,11 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
     d.splitk, d.accumulate, d.alpha = splitk, int(accumulate), alpha
     if conv is not None:
         d.Nb, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.R, d.S, d.stride, d.pad = conv
+    terms = _PRECISIONS[_PREC[0]]
+    if terms:
+        d.tile = tile or _FORCE_TILE[0]
+        check(_lib.lib().ick_gemm_bf16(ctypes.byref(d), terms, _st()), "ick_gemm_bf16")
+        return
     d.tile = tile or _FORCE_TILE[0] or _TUNED.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
     check(_lib.lib().ick_gemm_f32(ctypes.byref(d), _st()), "ick_gemm_f32")
 

@@ -1,7 +1,9 @@
-"""GPU parity of the fp32 MFMA implicit-GEMM family (csrc/igemm_f32.hip) through the C ABI,
-against float64 CPU references built from torch primitives.  Tolerance: 2e-5 relative to the
-output scale (exact-fp32 MFMA = fmaf chain; the reference path is fp32 too, so only summation
-order differs)."""
+"""GPU parity of the MFMA implicit-GEMM families (csrc/igemm_f32.hip, csrc/igemm_bf16.hip) through the C ABI,
+against float64 CPU references built from torch primitives.  Tolerances, relative to the output scale
+(max |err| / max |ref|):
+  f32     2e-5  exact-fp32 MFMA = fmaf chain; the reference path is fp32 too, so only summation order differs
+  bf16x3  2e-4  split-bf16 (hi*hi + hi*lo + lo*hi): ~2^-16 per product
+  bf16    1.5e-2  operands rounded to 8 significant bits (the reference's autocast regime), fp32 accumulate"""
 import math
 
 import pytest
@@ -10,7 +12,8 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOL = 2e-5
+TOLS = {"f32": 2e-5, "bf16x3": 2e-4, "bf16": 1.5e-2}
+TOL = 2e-5          # rebound per test by the `ops` fixture
 
 
 def rel_err(a, b):
@@ -19,10 +22,14 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.fixture(scope="module")
-def ops():
+@pytest.fixture(params=["f32", "bf16", "bf16x3"])
+def ops(request):
     from imagecaptioner_amd import ops as o
-    return o
+    global TOL
+    TOL = TOLS[request.param]
+    with o.precision(request.param):
+        yield o
+    TOL = TOLS["f32"]
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -37,8 +44,11 @@ def test_linear_fwd_bwd(ops, M, N, K):
     xd, wd, bd, rd = (t.cuda() for t in (x, w, b, r))
     for act, fn in ((0, lambda v: v), (1, torch.relu), (2, F.gelu), (3, torch.tanh)):
         y = ops.linear_fwd(xd, wd, bd, act=act, residual=rd)
-        ref = fn(x.double() @ w.double().T + b.double()) + r.double()
-        assert rel_err(y, ref) < TOL, f"fwd act={act}"
+        pre = x.double() @ w.double().T + b.double()
+        ref = fn(pre) + r.double()
+        # the rounding error lives on the pre-activation's scale (every activation here is 1-Lipschitz)
+        scale = max(1.0, (pre.abs().max() / ref.abs().max()).item()) if ops.gemm_precision() != "f32" else 1.0
+        assert rel_err(y, ref) < TOL * scale, f"fwd act={act}"
     dy = rnd(M, N, seed=5)
     dyd = dy.cuda()
     if K % 4 == 0 and N % 4 == 0:
@@ -58,6 +68,8 @@ def test_mfma_layout_asymmetric(ops):
     n = 128
     A = torch.eye(n)
     Bm = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 997.0   # B[i][j] != B[j][i]
+    if ops.gemm_precision() != "f32":
+        Bm = (torch.arange(n * n) % 251).float().reshape(n, n)            # exactly representable in bf16
     y = ops.linear_fwd(A.cuda(), Bm.cuda())         # y = A @ B^T = B^T
     assert torch.equal(y.cpu(), Bm.T.contiguous())
 
@@ -87,9 +99,9 @@ def test_attention_core(ops, B, H, Lq, Lk, d, causal):
     dkv = torch.zeros(B * Lk, 3 * E, device="cuda") if Lk != Lq else dq
     ops.attention_bwd(dO.cuda(), P, qd, 0, 3 * E, kvd, E, 3 * E, kvd, 2 * E, 3 * E,
                       dq, 0, 3 * E, dkv, E, 3 * E, dkv, 2 * E, 3 * E, B, H, Lq, Lk, d)
-    assert rel_err(dq[:, :E], qq.grad.transpose(1, 2).reshape(B * Lq, E)) < 5e-5
-    assert rel_err(dkv[:, E:2 * E], kk.grad.transpose(1, 2).reshape(B * Lk, E)) < 5e-5
-    assert rel_err(dkv[:, 2 * E:], vv.grad.transpose(1, 2).reshape(B * Lk, E)) < 5e-5
+    assert rel_err(dq[:, :E], qq.grad.transpose(1, 2).reshape(B * Lq, E)) < 2.5 * TOL
+    assert rel_err(dkv[:, E:2 * E], kk.grad.transpose(1, 2).reshape(B * Lk, E)) < 2.5 * TOL
+    assert rel_err(dkv[:, 2 * E:], vv.grad.transpose(1, 2).reshape(B * Lk, E)) < 2.5 * TOL
 
 
 CONVS = [  # (Nb, H, W, Cin, Cout, R, stride, pad) — every distinct ResNet-50 conv geometry at reduced batch
@@ -111,8 +123,8 @@ def test_conv_fwd_dgrad_wgrad(ops, Nb, H, W, Cin, Cout, R, stride, pad):
     y = ops.conv_fwd(xd, wd, stride, pad, stats=(stats[0], stats[1]))
     ref = F.conv2d(x.double(), w.double(), None, stride, pad)
     assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL
-    assert rel_err(stats[0], ref.sum((0, 2, 3))) < 1e-4 * max(1.0, ref.abs().sum((0, 2, 3)).max().item() / ref.sum((0, 2, 3)).abs().max().item())
-    assert rel_err(stats[1], (ref * ref).sum((0, 2, 3))) < 1e-4
+    assert rel_err(stats[0], ref.sum((0, 2, 3))) < max(1e-4, 5 * TOL) * max(1.0, ref.abs().sum((0, 2, 3)).max().item() / ref.sum((0, 2, 3)).abs().max().item())
+    assert rel_err(stats[1], (ref * ref).sum((0, 2, 3))) < max(1e-4, 5 * TOL)
     dy = rnd(*ref.shape, seed=3)
     dyd = dy.cuda().permute(0, 2, 3, 1).contiguous()
     res = rnd(Nb, H, W, Cin, seed=4).cuda()
@@ -123,7 +135,7 @@ def test_conv_fwd_dgrad_wgrad(ops, Nb, H, W, Cin, Cout, R, stride, pad):
     for sk in (1, 0):
         dw = torch.zeros_like(wd)
         ops.conv_wgrad(dyd, xd, dw, stride, pad, splitk=sk)
-        assert rel_err(dw.permute(0, 3, 1, 2), dw_ref) < 5e-5, f"wgrad splitk={sk}"
+        assert rel_err(dw.permute(0, 3, 1, 2), dw_ref) < 2.5 * TOL, f"wgrad splitk={sk}"
 
 
 def test_conv_stem_c4(ops):
@@ -137,6 +149,6 @@ def test_conv_stem_c4(ops):
     y = ops.conv_fwd(x4, w4, 2, 3, stats=(stats[0], stats[1]))
     ref = F.conv2d(x.double(), w.double(), None, 2, 3)
     assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL
-    assert rel_err(stats[1], (ref * ref).sum((0, 2, 3))) < 1e-4
+    assert rel_err(stats[1], (ref * ref).sum((0, 2, 3))) < max(1e-4, 5 * TOL)
     mp = ops.maxpool3x3s2(y)
     assert torch.equal(mp.permute(0, 3, 1, 2).cpu(), F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 3, 2, 1))

@@ -24,6 +24,9 @@ def timeit(fn, iters=20):
 
 
 def main():
+    prec = sys.argv[1] if len(sys.argv) > 1 else "f32"
+    ops.set_gemm_precision(prec)
+    print(f"precision {prec}")
     B = 64
     rows = []
     for (M, N, K) in [(4096, 4096, 4096), (12608, 1152, 384), (12608, 384, 384), (12608, 1536, 384), (12608, 384, 1536),
