@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream instead of a parallel graph branch")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3"],
                     help="student/projector GEMM arithmetic (teacher stays fp32 as in the reference); f32 = parity regime")
     args = ap.parse_args()
@@ -121,7 +122,8 @@ def main():
 
     student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev)    # identical init on every rank
     trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
-                        use_graph=not args.no_graph, precision=args.precision)
+                        use_graph=not args.no_graph, precision=args.precision,
+                        overlap_teacher=not args.no_overlap)
     images, caps = synthetic_batch(args.batch, VOCAB, T1, seed=1234, rank=rank)     # rank-specific shard of the global batch
     log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
     log("models built; first step (hipGraph capture) ...")

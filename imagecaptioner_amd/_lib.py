@@ -22,6 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libick.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "ick.h")
 
+ABI_VERSION = 2
 OP_NT, OP_NN, OP_TN, OP_CONV_FWD, OP_CONV_FWD_C4, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_CONV_DGRAD_S2 = range(8)
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = range(4)
 
@@ -41,7 +42,7 @@ class IckGemm(ctypes.Structure):
         ("Nb", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Cin", ctypes.c_int32),
         ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32), ("Cout", ctypes.c_int32),
         ("R", ctypes.c_int32), ("S", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
-        ("tile", ctypes.c_int32),
+        ("tile", ctypes.c_int32), ("stat_copies", ctypes.c_int32), ("stat_stride", ctypes.c_int64),
     ]
 
 
@@ -83,7 +84,7 @@ def lib() -> ctypes.CDLL:
         fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
         fn.restype = ctypes.c_char_p if ret != "int" else ctypes.c_int
         fn.argtypes = [ctypes.c_void_p if t == "ptr" else _CTYPE[t] for t in types]
-    if L.ick_abi_version() != 1:
+    if L.ick_abi_version() != ABI_VERSION:
         raise RuntimeError("libick.so ABI version mismatch")
     _lib = L
     return L

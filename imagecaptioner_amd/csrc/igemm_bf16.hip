@@ -401,7 +401,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
       if (p.stat_sum) {
         ssum += __shfl_xor(ssum, 32);
         ssq += __shfl_xor(ssq, 32);
-        if (lane < 32 && nok) { atomicAdd(p.stat_sum + n, (double)ssum); atomicAdd(p.stat_sq + n, (double)ssq); }
+        if (lane < 32 && nok) {
+          const long so = (long)(tile_m % p.stat_copies) * p.stat_stride + n;   // copy of this row tile
+          atomicAdd(p.stat_sum + so, (double)ssum); atomicAdd(p.stat_sq + so, (double)ssq);
+        }
       }
     }
   };

@@ -19,6 +19,7 @@
 // Global->LDS is software pipelined through registers (issue tile t+1's loads, run tile t's
 // MFMAs, then write t+1 into the other LDS buffer): one barrier per k-tile.
 #include "igemm_params.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -371,7 +372,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
       if (p.stat_sum) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
         ssum += __shfl_xor(ssum, 32);
         ssq += __shfl_xor(ssq, 32);
-        if (lane < 32 && nok) { atomicAdd(p.stat_sum + n, (double)ssum); atomicAdd(p.stat_sq + n, (double)ssq); }
+        if (lane < 32 && nok) {
+          const long so = (long)(tile_m % p.stat_copies) * p.stat_stride + n;   // copy of this row tile
+          atomicAdd(p.stat_sum + so, (double)ssum); atomicAdd(p.stat_sq + so, (double)ssq);
+        }
       }
     }
   };
@@ -416,49 +420,65 @@ int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
 
 }  // namespace
 
-extern "C" int ick_gemm_f32(const IckGemm* d, void* stream) {
+namespace ickg {
+bool glds_eligible(const IckGemm* d);                                   // igemm_f32_glds.hip
+int run_glds(const IckGemm* d, const P& p, int nz, hipStream_t st);
+}
+
+// the LDS-DMA kernel (igemm_f32_glds.hip) is the default; IckGemm.tile bit 8 or ICK_NO_GLDS=1 selects this file's
+// register-staged kernel (kept for shapes whose 16-byte chunks would straddle the K end or a filter tap, and for A/B runs)
+static bool want_glds(const IckGemm* d) {
+  static const bool off = [] { const char* e = getenv("ICK_NO_GLDS"); return e && e[0] == '1'; }();
+  return !off && !(d->tile & 256) && glds_eligible(d);
+}
+
+extern "C" int ick_gemm_f32(const IckGemm* d0, void* stream) {
+  ICK_REQUIRE(d0 != nullptr, "ick_gemm_f32: null descriptor");
+  const bool glds = want_glds(d0);
+  IckGemm dd = *d0; dd.tile &= 255;
+  const IckGemm* d = &dd;
   P p; int nz = 1;
-  if (int rc = prepare(d, BK, p, nz, "ick_gemm_f32")) return rc;
+  if (int rc = prepare(d, glds ? 32 : BK, p, nz, "ick_gemm_f32")) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d->op) {
     case ICK_OP_NT:
       ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "NT: lda, ldb must be multiples of 4 (rows readable up to roundup4(K))");
       ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "NT: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_NT>(p, nz, st, d->tile);
+      return glds ? run_glds(d, p, nz, st) : dispatch_tile<ICK_OP_NT>(p, nz, st, d->tile);
     case ICK_OP_NN:
       ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "NN: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
       ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "NN: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_NN>(p, nz, st, d->tile);
+      return glds ? run_glds(d, p, nz, st) : dispatch_tile<ICK_OP_NN>(p, nz, st, d->tile);
     case ICK_OP_TN:
       ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "TN: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
       ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "TN: batch strides must be multiples of 4");
-      return dispatch_tile<ICK_OP_TN>(p, nz, st, d->tile);
+      return glds ? run_glds(d, p, nz, st) : dispatch_tile<ICK_OP_TN>(p, nz, st, d->tile);
     case ICK_OP_CONV_FWD:
-      ICK_REQUIRE(p.Cin % BK == 0, "CONV_FWD: Cin=%d must be a multiple of %d", p.Cin, BK);
+      ICK_REQUIRE(p.Cin % 16 == 0, "CONV_FWD: Cin=%d must be a multiple of 16", p.Cin);
       ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * p.Cin && p.ldb == p.K,
                   "CONV_FWD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_FWD>(p, nz, st, d->tile);
+      return glds ? run_glds(d, p, nz, st) : dispatch_tile<ICK_OP_CONV_FWD>(p, nz, st, d->tile);
     case ICK_OP_CONV_FWD_C4:
       ICK_REQUIRE(p.Cin == 4, "CONV_FWD_C4: Cin must be 4");
       ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * 4 && p.ldb == p.K,
                   "CONV_FWD_C4: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_FWD_C4>(p, nz, st, d->tile);
+      return glds ? run_glds(d, p, nz, st) : dispatch_tile<ICK_OP_CONV_FWD_C4>(p, nz, st, d->tile);
     case ICK_OP_CONV_DGRAD:
-      ICK_REQUIRE(p.Cout % BK == 0 && p.Cin % 4 == 0, "CONV_DGRAD: Cout %% 16 and Cin %% 4 required");
+      ICK_REQUIRE(p.Cout % 16 == 0 && p.Cin % 4 == 0, "CONV_DGRAD: Cout %% 16 and Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Nb * p.H * p.W && p.N == p.Cin && p.K == p.R * p.S * p.Cout,
                   "CONV_DGRAD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_DGRAD>(p, nz, st, d->tile);
+      return glds ? run_glds(d, p, nz, st) : dispatch_tile<ICK_OP_CONV_DGRAD>(p, nz, st, d->tile);
     case ICK_OP_CONV_DGRAD_S2:
       ICK_REQUIRE(p.stride == 2 && p.H % 2 == 0 && p.W % 2 == 0, "CONV_DGRAD_S2: stride 2 and even H, W required");
-      ICK_REQUIRE(p.Cout % BK == 0 && p.Cin % 4 == 0, "CONV_DGRAD_S2: Cout %% 16 and Cin %% 4 required");
+      ICK_REQUIRE(p.Cout % 16 == 0 && p.Cin % 4 == 0, "CONV_DGRAD_S2: Cout %% 16 and Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Nb * (p.H / 2) * (p.W / 2) && p.N == p.Cin && p.K == p.R * p.S * p.Cout && nz == 1 &&
                   p.splitk == 1, "CONV_DGRAD_S2: M must be the rows of ONE parity class; no batching / split-K");
-      return dispatch_tile<ICK_OP_CONV_DGRAD_S2>(p, 4, st, d->tile);
+      return glds ? run_glds(d, p, 4, st) : dispatch_tile<ICK_OP_CONV_DGRAD_S2>(p, 4, st, d->tile);
     case ICK_OP_CONV_WGRAD:
       ICK_REQUIRE(p.Cout % 4 == 0 && p.Cin % 4 == 0, "CONV_WGRAD: Cout %% 4 and Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Cout && p.N == p.R * p.S * p.Cin && p.K == p.Nb * p.Ho * p.Wo && p.lda == p.Cout,
                   "CONV_WGRAD: M/N/K do not match the geometry");
-      return dispatch_tile<ICK_OP_CONV_WGRAD>(p, nz, st, d->tile);
+      return glds ? run_glds(d, p, nz, st) : dispatch_tile<ICK_OP_CONV_WGRAD>(p, nz, st, d->tile);
     default:
       return ick::fail(-1, "ick_gemm_f32: unknown op %d", d->op);
   }

@@ -15,6 +15,7 @@ struct P {  // kernel parameters (by value)
   int splitk, kps, accumulate, act, tiles_n;
   float alpha;
   int Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
+  int stat_copies; long stat_stride;
 };
 
 // which fetch pattern each op uses for its A and B operands
@@ -61,6 +62,8 @@ inline int prepare(const IckGemm* d, int bk, P& p, int& nz, const char* who) {
   p = P{};
   p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
   p.stat_sum = d->stat_sum; p.stat_sq = d->stat_sq;
+  p.stat_copies = d->stat_copies > 1 ? d->stat_copies : 1; p.stat_stride = d->stat_stride;
+  ICK_REQUIRE(p.stat_copies == 1 || p.stat_stride >= d->N, "%s: stat_stride must be >= N", who);
   p.M = d->M; p.N = d->N; p.K = d->K;
   p.lda = d->lda; p.ldb = d->ldb; p.ldc = d->ldc; p.ldr = d->ldr;
   p.batch_inner = d->batch_inner > 0 ? d->batch_inner : 1;

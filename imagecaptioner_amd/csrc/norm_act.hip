@@ -71,15 +71,22 @@ __global__ void vit_assemble_kernel(const float* __restrict__ patch, const float
 // ------------------------------------------------------------------ BatchNorm
 // finalize batch statistics gathered by the conv epilogue: mean/var -> (scale, shift), saved mean / invstd,
 // running-stat update with the unbiased variance (nn.BatchNorm2d train mode, momentum 0.1)
-__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sq, float count,
+// the conv epilogue may spread its fp64 atomics over `copies` accumulator rows (IckGemm.stat_copies): fold them
+__device__ __forceinline__ double fold_copies(const double* __restrict__ a, int c, int copies, long stride) {
+  double s = a[c];
+  for (int r = 1; r < copies; ++r) s += a[r * stride + c];
+  return s;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sq, int copies, long stride, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
                                    float* __restrict__ sinv, int C) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double meand = sum[c] / (double)count;
-  double vard = sq[c] / (double)count - meand * meand;      // fp64 accumulators: no cancellation
+  const double meand = fold_copies(sum, c, copies, stride) / (double)count;
+  double vard = fold_copies(sq, c, copies, stride) / (double)count - meand * meand;      // fp64 accumulators: no cancellation
   vard = vard > 0.0 ? vard : 0.0;
   const float mean = (float)meand;
   const float var = (float)vard;
@@ -126,31 +133,60 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
 }
 
 __global__ void bn_train_apply_kernel(const float* __restrict__ x, const double* __restrict__ sum,
-                                      const double* __restrict__ sq, float count, const float* __restrict__ gamma,
+                                      const double* __restrict__ sq, int copies, long stride, float count, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                       float momentum, float eps, const float* __restrict__ res, float* __restrict__ y,
                                       float* __restrict__ smean, float* __restrict__ sinv, long total4, int C4, int relu) {
   const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const int c4 = (int)(i0 % C4);
   float sc[4], sh[4];
+  if (copies > 1) {
+    // large-M layers (few channels, several accumulator copies): fold the copies once per block, cooperatively, into
+    // LDS — per THREAD the 2 x copies fp64 loads per channel would dwarf the elementwise work
+    __shared__ float s_sc[1024], s_sh[1024];
+    const int C = C4 * 4;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      const double meand = fold_copies(sum, c, copies, stride) / (double)count;
+      double vard = fold_copies(sq, c, copies, stride) / (double)count - meand * meand;
+      vard = vard > 0.0 ? vard : 0.0;
+      const float inv = (float)(1.0 / sqrt(vard + (double)eps));
+      const float g = gamma[c];
+      s_sc[c] = g * inv;
+      s_sh[c] = beta[c] - (float)meand * g * inv;
+      if (blockIdx.x == 0) {    // exactly one block publishes the statistics
+        smean[c] = (float)meand;
+        sinv[c] = inv;
+        if (rmean) {
+          const float var = (float)vard;
+          const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+          rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)meand;
+          rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        }
+      }
+    }
+    __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = c4 * 4 + k;
-    const double meand = sum[c] / (double)count;
-    double vard = sq[c] / (double)count - meand * meand;
-    vard = vard > 0.0 ? vard : 0.0;
-    const float inv = (float)(1.0 / sqrt(vard + (double)eps));
-    const float g = gamma[c];
-    sc[k] = g * inv;
-    sh[k] = beta[c] - (float)meand * g * inv;
-    if (i0 < C4) {            // exactly one thread per channel group publishes the statistics
-      smean[c] = (float)meand;
-      sinv[c] = inv;
-      if (rmean) {
-        const float var = (float)vard;
-        const float unb = count > 1.f ? var * count / (count - 1.f) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)meand;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    for (int k = 0; k < 4; ++k) { sc[k] = s_sc[c4 * 4 + k]; sh[k] = s_sh[c4 * 4 + k]; }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = c4 * 4 + k;
+      const double meand = sum[c] / (double)count;
+      double vard = sq[c] / (double)count - meand * meand;
+      vard = vard > 0.0 ? vard : 0.0;
+      const float inv = (float)(1.0 / sqrt(vard + (double)eps));
+      const float g = gamma[c];
+      sc[k] = g * inv;
+      sh[k] = beta[c] - (float)meand * g * inv;
+      if (i0 < C4) {            // exactly one thread per channel group publishes the statistics
+        smean[c] = (float)meand;
+        sinv[c] = inv;
+        if (rmean) {
+          const float var = (float)vard;
+          const float unb = count > 1.f ? var * count / (count - 1.f) : var;
+          rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)meand;
+          rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        }
       }
     }
   }
@@ -503,12 +539,12 @@ int ick_vit_assemble(const float* patch, const float* cls, const float* pos, flo
   return ick::launch_status("vit_assemble");
 }
 
-int ick_bn_finalize(const double* sum, const double* sq, float count, const float* gamma, const float* beta, float* rmean,
+int ick_bn_finalize(const double* sum, const double* sq, int stat_copies, int64_t stat_stride, float count, const float* gamma, const float* beta, float* rmean,
                     float* rvar, float momentum, float eps, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int C, void* stream) {
   ICK_REQUIRE(sum && sq && gamma && beta && scale && shift && save_mean && save_invstd && C > 0 && count > 0,
               "ick_bn_finalize: bad arguments");
-  ICK_LAUNCH(bn_finalize_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum, sq, count, gamma, beta, rmean, rvar,
+  ICK_LAUNCH(bn_finalize_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum, sq, stat_copies > 1 ? stat_copies : 1, (long)stat_stride, count, gamma, beta, rmean, rvar,
                      momentum, eps, scale, shift, save_mean, save_invstd, C);
   return ick::launch_status("bn_finalize");
 }
@@ -559,7 +595,7 @@ int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const floa
 // train-mode BatchNorm forward in ONE pass over the raw conv output: every thread derives scale/shift of its own
 // 4 channels from the fp64 batch sums the conv epilogue produced (the grid stride is a multiple of C/4, so a
 // thread's channels never change), block 0 also stores mean / invstd for backward and updates the running stats.
-int ick_bn_train_apply(const float* x, const double* sum, const double* sq, const float* gamma, const float* beta,
+int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                        float* y, float* save_mean, float* save_invstd, long M, int C, int relu, void* stream) {
   ICK_REQUIRE(x && sum && sq && gamma && beta && y && save_mean && save_invstd && M > 0 && C % 4 == 0 && (C / 4) <= 1024 &&
@@ -569,7 +605,8 @@ int ick_bn_train_apply(const float* x, const double* sum, const double* sq, cons
   int grid = grid_for(total4);
   const int q = C4 > NT ? C4 / NT : 1;          // grid * NT must be a multiple of C4
   grid = (grid + q - 1) / q * q;
-  ICK_LAUNCH(bn_train_apply_kernel, dim3(grid), dim3(NT), 0, ST, x, sum, sq, (float)M, gamma, beta, running_mean,
+  ICK_REQUIRE(stat_copies <= 1 || C <= 1024, "ick_bn_train_apply: accumulator copies are supported up to C = 1024 (C = %d)", C);
+  ICK_LAUNCH(bn_train_apply_kernel, dim3(grid), dim3(NT), 0, ST, x, sum, sq, stat_copies > 1 ? stat_copies : 1, (long)stat_stride, (float)M, gamma, beta, running_mean,
              running_var, momentum, eps, residual, y, save_mean, save_invstd, total4, C4, relu);
   return ick::launch_status("bn_train_apply");
 }

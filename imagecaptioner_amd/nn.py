@@ -254,7 +254,10 @@ def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool,
     w = w_packed if w_packed is not None else conv.packed()
     if train:
         C = w.shape[0]
-        stats = arena.take(2, C) if arena is not None else torch.zeros(2, C, dtype=torch.float64, device=x.device)
+        Ho, Wo = ops.conv_out_hw(x.shape[1], x.shape[2], w.shape[1], w.shape[2], conv.stride, conv.padding)
+        R = ops.stat_copies(x.shape[0] * Ho * Wo)
+        stats = (arena.take(2 * R, C) if arena is not None else
+                 torch.zeros(2 * R, C, dtype=torch.float64, device=x.device)).view(2, R, C)
         raw = ops.conv_fwd(x, w, conv.stride, conv.padding, stats=(stats[0], stats[1]))
         y, mean, inv = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
                                           bn.eps, residual, relu)
@@ -324,7 +327,7 @@ class ResNetTrunkFn(Function):
         if train:
             nch = 64 + sum(b.bn1.weight.numel() + b.bn2.weight.numel() + b.bn3.weight.numel() +
                            (b.downsample[1].weight.numel() if b.downsample is not None else 0) for b in blocks)
-            arena, counters = _Arena(2 * nch, torch.float64, images.device), []
+            arena, counters = _Arena(2 * nch * 8, torch.float64, images.device), []   # up to 8 accumulator copies per BN (ops.stat_copies)
         cb = lambda x, c, b, relu, res: conv_bn(x, c, b, relu, res, train, arena=arena, counters=counters)
         y, _, _, _ = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters)
         y = ops.maxpool3x3s2(y)

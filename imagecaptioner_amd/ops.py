@@ -53,6 +53,8 @@ def _load_tuned():
     import json
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles.json")
+    if os.environ.get("ICK_NO_TUNED") == "1":      # A/B runs: the library's own tile model only
+        return {}
     try:
         return {k: int(v) for k, v in json.load(open(path)).items()}
     except FileNotFoundError:
@@ -99,10 +101,11 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
              alpha: float = 1.0, batch: Tuple[int, int] = (1, 1),
              strides: Tuple[int, int, int, int, int, int] = (0, 0, 0, 0, 0, 0), splitk: int = 1,
              accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
-             conv: Optional[Tuple[int, ...]] = None, tile: int = 0) -> None:
+             conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0) -> None:
     d = IckGemm()
     d.A, d.B, d.C = A, B, C
     d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
+    d.stat_copies, d.stat_stride = stat_copies, stat_stride
     d.op, d.act = op, act
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
@@ -294,7 +297,8 @@ def conv_out_hw(H: int, W: int, R: int, S: int, stride: int, pad: int) -> Tuple[
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
              ) -> torch.Tensor:
     """x (Nb,H,W,Cin) physical NHWC contiguous; w physical (Cout,R,S,Cin); returns raw y (Nb,Ho,Wo,Cout) and
-    optionally accumulates per-channel sum / sum of squares (BatchNorm batch statistics) into `stats`."""
+    optionally accumulates per-channel sum / sum of squares (BatchNorm batch statistics) into `stats`:
+    (sum, sq) fp64 [Cout] each, or fp64 [Cout] x R copies each as rows of a (R, Cout) tensor (see stat_copies())."""
     Nb, H, W, Cin = x.shape
     Cout, R, S, Cin2 = w.shape
     assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous()
@@ -303,9 +307,18 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Opt
     op = OP_CONV_FWD_C4 if Cin == 4 else OP_CONV_FWD
     K = R * S * Cin
     gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout,
-             stat_sum=_ptr(stats[0]) if stats else None, stat_sq=_ptr(stats[1]) if stats else None,
+             stat_sum=_ptr(stats[0]) if stats is not None else None, stat_sq=_ptr(stats[1]) if stats is not None else None,
+             stat_copies=stats[0].shape[0] if (stats is not None and stats[0].dim() == 2) else 1, stat_stride=Cout,
              conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
     return y
+
+
+def stat_copies(rows: int) -> int:
+    """Number of accumulator copies for the BatchNorm batch statistics of a conv with `rows` output pixels: every
+    128-row tile of the grid adds 2 x Cout fp64 atomics to the SAME few cache lines; beyond a few hundred tiles that
+    serialises in L2 (measured: 37-52 % of a 56x56 conv's time).  Copies spread the adds; consumers fold them."""
+    tiles = rows // 128
+    return 1 if tiles < 64 else min(8, max(2, tiles // 32))
 
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride: int, pad: int,
@@ -353,7 +366,8 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int,
 def bn_finalize(ssum, ssq, count, gamma, beta, rmean, rvar, momentum, eps):
     C = gamma.numel()
     co = empty(4, C, device=gamma.device)  # scale, shift, mean, invstd
-    check(_lib.lib().ick_bn_finalize(ssum.data_ptr(), ssq.data_ptr(), float(count), gamma.data_ptr(), beta.data_ptr(),
+    copies = ssum.shape[0] if ssum.dim() == 2 else 1
+    check(_lib.lib().ick_bn_finalize(ssum.data_ptr(), ssq.data_ptr(), copies, C, float(count), gamma.data_ptr(), beta.data_ptr(),
                                      _ptr(rmean), _ptr(rvar), momentum, eps, co[0].data_ptr(), co[1].data_ptr(),
                                      co[2].data_ptr(), co[3].data_ptr(), C, _st()), "ick_bn_finalize")
     return co
@@ -399,7 +413,8 @@ def bn_train_apply(raw, stats, gamma, beta, rmean, rvar, momentum, eps, residual
     C = raw.shape[-1]
     y = torch.empty_like(raw)
     sv = empty(2, C, device=raw.device)
-    check(_lib.lib().ick_bn_train_apply(raw.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), gamma.data_ptr(),
+    copies = stats[0].shape[0] if stats[0].dim() == 2 else 1
+    check(_lib.lib().ick_bn_train_apply(raw.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), copies, C, gamma.data_ptr(),
                                         beta.data_ptr(), _ptr(rmean), _ptr(rvar), momentum, eps, _ptr(residual), y.data_ptr(),
                                         sv[0].data_ptr(), sv[1].data_ptr(), raw.numel() // C, C, int(relu), _st()),
           "ick_bn_train_apply")

@@ -95,11 +95,12 @@ class KDTrainer:
     def __init__(self, student, teacher, projectors: Dict[str, nn.Module], *, vocab_size: int, alpha=0.7, beta=0.2,
                  gamma=0.1, temperature=4.0, learning_rate=2e-4, weight_decay=0.01, max_norm=1.0, batches_per_epoch=1000,
                  batch_size: int = 64, t_plus_1: int = 16, use_graph: bool = True, process_group=None,
-                 precision: str = "f32", teacher_precision: str = "f32"):
+                 precision: str = "f32", teacher_precision: str = "f32", overlap_teacher: bool = True):
         """precision: arithmetic of the student + projector contractions, forward and backward ("f32" exact, "bf16" =
         the reference's autocast regime :271-285 with fp32 master weights, "bf16x3" split-bf16); the teacher runs
         outside autocast in fp32 in the reference (:265-268) -> teacher_precision defaults to "f32"."""
         self.precision, self.teacher_precision = precision, teacher_precision
+        self.side_stream = torch.cuda.Stream() if (overlap_teacher and torch.cuda.is_available()) else None
         self.student, self.teacher, self.projectors = student, teacher, projectors
         self.device = next(student.parameters()).device
         self.teacher_wrapper = TeacherWrapper(teacher)
@@ -139,10 +140,25 @@ class KDTrainer:
         self.flat.grad.zero_()
         self.drop_step += 1
         cin, ctg = self.captions[:-1], self.captions[1:]
-        with ops.precision(self.teacher_precision):
-            t_out = self.teacher_wrapper(self.images, cin)
+        # The frozen teacher's forward does not depend on the student: it runs on a side HIP stream (a parallel
+        # branch of the captured graph), so its large GEMMs fill the CUs that the student's latency-bound
+        # per-token decoder kernels leave idle.  Joined before the loss.
+        side = self.side_stream
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side), ops.precision(self.teacher_precision):
+                t_out = self.teacher_wrapper(self.images, cin)
+        else:
+            with ops.precision(self.teacher_precision):
+                t_out = self.teacher_wrapper(self.images, cin)
         with ops.precision(self.precision):
             logits, enc, hids, _ = self.student(self.images, cin)
+            if side is not None:
+                cur.wait_stream(side)
+                for v in t_out.values():
+                    if torch.is_tensor(v):
+                        v.record_stream(cur)
             s_out = {"logits": logits, "encoder_features": enc, "hidden_states": hids}
             t_out["encoder_features"] = self.projectors["encoder"](t_out["encoder_features"])
             out5 = self.loss.forward_device(s_out, t_out, ctg)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ICK_ABI_VERSION 1
+#define ICK_ABI_VERSION 2
 
 const char* ick_last_error(void);
 int ick_abi_version(void);
@@ -68,7 +68,9 @@ typedef struct IckGemm {
   float alpha;
   /* convolution geometry (ICK_OP_CONV_*): X [Nb][H][W][Cin], Y [Nb][Ho][Wo][Cout] */
   int32_t Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
-  int32_t tile;                                 /* 0 = choose by the wave-quantisation model; 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128 */
+  int32_t tile;                                 /* 0 = choose by the wave-quantisation model; 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128; +16 = three LDS buffers (LDS-DMA kernel); +256 = register-staged kernel */
+  int32_t stat_copies;                          /* <= 1: one accumulator row; R > 1: stat_sum/stat_sq are [R][stat_stride] and the row-tile t of the grid adds into copy t % R (spreads the fp64 atomics of large-M convolutions over R x as many cache lines; consumers sum the copies) */
+  int64_t stat_stride;                          /* elements between two copies (>= N) */
 } IckGemm;
 
 int ick_gemm_f32(const IckGemm* desc, void* stream);
@@ -99,8 +101,8 @@ int ick_vit_assemble(const float* patch, const float* cls, const float* pos, flo
 /* ------------------------------------------------------------------ BatchNorm2d over NHWC rows [M = B*H*W][C]
  * nn.BatchNorm2d inside torchvision resnet50 (student_model.py:16-20,57); train mode = batch statistics + running-stat
  * update, also for the "frozen" stem.  Batch sums come from the conv epilogue (IckGemm.stat_*). */
-int ick_bn_finalize(const double* sum, const double* sq, float count, const float* gamma, const float* beta,
-                    float* running_mean, float* running_var, float momentum, float eps,
+int ick_bn_finalize(const double* sum, const double* sq, int stat_copies, int64_t stat_stride, float count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* save_mean, float* save_invstd, int C, void* stream);
 int ick_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps,
                        float* scale, float* shift, int C, void* stream);
@@ -111,7 +113,7 @@ int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const flo
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const float* sum_g, const float* sum_gx, float* dx, float* g_out,
                      int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, void* stream); /* dgamma/dbeta (optional) += the two sums */
-int ick_bn_train_apply(const float* x, const double* sum, const double* sq, const float* gamma, const float* beta,
+int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                        float* y, float* save_mean, float* save_invstd, int64_t M, int C, int relu, void* stream); /* bn_finalize + scale_shift_act in one pass */
 int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream); /* nn.MaxPool2d(3,2,1), NHWC */

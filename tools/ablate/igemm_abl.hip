@@ -18,7 +18,7 @@
 //     fetched as float4 along x and stored with one ds_write_b128 (row pitch BX+4).
 // Global->LDS is software pipelined through registers (issue tile t+1's loads, run tile t's
 // MFMAs, then write t+1 into the other LDS buffer): one barrier per k-tile.
-#include "../../imagecaptioner_amd/csrc/ick_common.h"
+#include "../../imagecaptioner_amd/csrc/igemm_params.h"
 #ifndef ABL
 #define ABL 0
 #endif
@@ -35,51 +35,7 @@ constexpr int NT = 256;
 #endif
 constexpr int STASH_AT = ICK_STASH_AT;   // k offset inside a tile after which the next tile is written to LDS
 
-struct P {  // kernel parameters (by value)
-  const float* A; const float* B; float* C;
-  const float* bias; const float* residual; double* stat_sum; double* stat_sq;
-  int M, N, K;
-  long lda, ldb, ldc, ldr;
-  int batch_inner;
-  long sAo, sAi, sBo, sBi, sCo, sCi;
-  int splitk, kps, accumulate, act, tiles_n;
-  float alpha;
-  int Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
-};
-
-// which fetch pattern each op uses for its A and B operands
-__host__ __device__ constexpr bool a_kcontig(int op) { return op != ICK_OP_TN && op != ICK_OP_CONV_WGRAD; }
-__host__ __device__ constexpr bool is_dgrad(int op) { return op == ICK_OP_CONV_DGRAD || op == ICK_OP_CONV_DGRAD_S2; }
-__host__ __device__ constexpr bool b_kcontig(int op) {
-  return op == ICK_OP_NT || op == ICK_OP_CONV_FWD || op == ICK_OP_CONV_FWD_C4;
-}
-
-// Branch-free guarded fetch: a lane whose element is out of range reads a valid dummy address and its value is
-// zeroed where it is CONSUMED (the LDS stash), so the 16-byte loads of tile t+1 stay in flight across tile t's MFMAs.
-// (A branchy `ok ? load : 0` makes hipcc emit s_waitcnt vmcnt(0) right behind the loads: load->compute serialised.)
-__device__ __forceinline__ float4 ldg4u(const float* p, bool ok, const float* safe) {
-  return *reinterpret_cast<const float4*>(ok ? p : safe);
-}
-__device__ __forceinline__ float4 keep_if(float4 v, bool ok) {
-  return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
-}
-// k-contiguous rows whose valid range ends at kend (any kend: the row pitch is a multiple of 4, so the 16-byte load
-// stays inside the row): zero the components at k+1..k+3 that lie past kend
-__device__ __forceinline__ float4 ktail(float4 v, int k, int kend) {
-  if (k + 3 >= kend) {
-    if (k + 1 >= kend) v.y = 0.f;
-    if (k + 2 >= kend) v.z = 0.f;
-    v.w = 0.f;
-  }
-  return v;
-}
-
-__device__ __forceinline__ float act_fn(float v, int act) {
-  if (act == ICK_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == ICK_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-  if (act == ICK_ACT_TANH) return tanhf(v);
-  return v;
-}
+using namespace ickg;
 
 template <int OP, int BM, int BN>
 __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {

@@ -41,7 +41,8 @@ big = torch.empty(1 << 28, device="cuda").normal_()         # 1 GiB scratch for 
 out = torch.empty(1 << 27, device="cuda")
 stat = torch.zeros(2, 4096, dtype=torch.float64, device="cuda")
 rows = []
-TN_ = ["model", "128x128", "64x64", "128x64", "64x128"]
+TN_ = ["model", "128x128", "64x64", "128x64", "64x128", "3b64x64", "3b128x64", "3b64x128", "r128x128", "r64x64", "r128x64", "r64x128"]
+TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260]   # +16: three LDS buffers; +256: the register-staged kernel
 
 
 def timeit(f, iters=10):
@@ -67,27 +68,27 @@ for r, n in cnt.items():
         kw["stat_sum"], kw["stat_sq"] = stat[0].data_ptr(), stat[1].data_ptr()
     a, b = big.data_ptr(), big.data_ptr() + (1 << 29)
     ts = []
-    for tile in range(5):
+    for tile in TILES:
         ts.append(timeit(lambda: orig(op, a, b, out.data_ptr(), M, N, K, lda, ldb, ldc, tile=tile, **kw)))
     nb = batch[0] * batch[1]
     fl = 2.0 * M * N * K * nb * (0.75 if op == 4 else 1.0)
-    best = min(range(1, 5), key=lambda i: ts[i])
+    best = min(range(1, len(TILES)), key=lambda i: ts[i])
     rows.append((ts[0] * n, n, ts[0], fl / ts[0] / 1e12, OPN[op], M, N, K, nb, splitk, conv, ts, best))
 rows.sort(reverse=True, key=lambda r: r[0])
 tot = sum(r[0] for r in rows)
 totb = sum(r[11][r[12]] * r[1] for r in rows)
 print(f"sum of isolated igemm time per step: model {tot * 1e3:.2f} ms; best tile per shape {totb * 1e3:.2f} ms")
-print(f"{'total us':>9s} {'n':>4s} {'model us':>8s} {'TF/s':>6s}  {'128x128':>8s} {'64x64':>8s} {'128x64':>8s} {'64x128':>8s} best     op          M      N      K  batch splitk conv")
+print(f"{'total us':>9s} {'n':>4s} {'model us':>8s} {'TF/s':>6s}  " + " ".join(f"{x:>8s}" for x in TN_[1:]) + " best     op          M      N      K  batch splitk conv")
 for tt, n, t, tf, opn, M, N, K, nb, sk, conv, ts, best in rows[:90]:
     print(f"{tt * 1e6:9.0f} {n:4d} {t * 1e6:8.1f} {tf:6.1f}  " + " ".join(f"{x * 1e6:8.1f}" for x in ts[1:]) +
-          f" {TN_[best]:8s} {opn:11s} {M:6d} {N:6d} {K:6d} {nb:5d} {sk:5d}  {conv if conv else ''}")
+          f" {TN_[best]:9s} {opn:11s} {M:6d} {N:6d} {K:6d} {nb:5d} {sk:5d}  {conv if conv else ''}")
 
 # ---- autotune table: best tile per descriptor where it beats the model's choice by > 3 %
 import json
 table = {}
 for tt, n, t, tf, opn, M, N, K, nb, sk, conv, ts, best in rows:
     if ts[best] < 0.97 * ts[0]:
-        table[f"{OPN.index(opn)}:{M}:{N}:{K}:{nb}:{sk}"] = best
+        table[f"{OPN.index(opn)}:{M}:{N}:{K}:{nb}:{sk}"] = TILES[best]
 out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"tuned_tiles_B{B}.json")
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(table, open(out_path, "w"), indent=0, sort_keys=True)
