@@ -91,6 +91,85 @@ def cpu_baseline(batch: int = 16):
                       f"no optimizer), torch {torch.__version__} CPU eager"}
 
 
+def run_kd(args, precision, dev, rank, world, log):
+    """W untimed + K timed KD train steps (hipGraph replays) at the given student precision.  Returns
+    (images/s whole job, wall seconds for K steps [max over ranks], device ms for K steps on this rank, loss dict)."""
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+
+    student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev)    # identical init on every rank
+    trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
+                        use_graph=not args.no_graph, precision=precision, overlap_teacher=not args.no_overlap)
+    images, caps = synthetic_batch(args.batch, VOCAB, T1, seed=1234, rank=rank)     # rank-specific shard of the global batch
+    log(f"[{precision}] models built; first step (hipGraph capture) ...")
+    trainer.train_step(images.to(dev), caps.to(dev))                                # inputs resident in HBM from here on
+    torch.cuda.synchronize()
+    for _ in range(max(0, args.warmup - 1)):
+        trainer.train_step()
+    torch.cuda.synchronize()
+    log(f"[{precision}] timing {args.steps} steps ...")
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        trainer.train_step()
+    ev1.record()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)                      # HIP events on the stream the step's graphs are launched on
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = trainer.loss_dict()
+    del trainer, student, teacher, projectors
+    torch.cuda.empty_cache()
+    return world * args.batch * args.steps / dt, dt, dev_ms, loss
+
+
+def run_cfg2(dev, log, batch=128, max_length=20, iters=10):
+    """BASELINE.json configs[1]: student ResNet50+LSTM (256/512/2-layer) forward + batched greedy decode in bf16 at
+    batch 128 on one GPU (captured once into a hipGraph, no per-token host sync).  8.87 algorithmic GFLOP/image
+    (encoder + refinement 8.28 + 20 tokens x 0.0297)."""
+    from imagecaptioner_amd import ops
+    from imagecaptioner_amd.student_model import CaptioningStudent
+    from imagecaptioner_amd.utils.seeded_init import apply_seeded_init, synthetic_batch
+    m = apply_seeded_init(CaptioningStudent(VOCAB, 256, 512, 2), 0).to(dev).eval()
+    images, _ = synthetic_batch(batch, VOCAB, T1, seed=4321)
+    images = images.to(dev)
+    with ops.precision("bf16"):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            m.generate(images, max_length)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            ids, _ = m.generate(images, max_length)
+    g.replay()
+    torch.cuda.synchronize()
+    log("[cfg2] timing the captured forward + greedy decode ...")
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    out = {"workload": "cfg2: student ResNet50+LSTM (256/512/2-layer, refinement on) eval forward + 20-step batched greedy decode, "
+                       f"batch {batch}, 1 GPU, hipGraph", "dtype": "bf16 (fp32 accumulate)", "images_per_s": round(batch / dt, 1),
+           "decode_tokens_per_s": round(batch * max_length / dt, 1), "ms_per_batch": round(dt * 1e3, 3),
+           "achieved_TFLOPs": round(8.87 * batch / dt / 1e3, 2)}
+    del g, m
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,6 +178,7 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (bf16 step, cfg2 decode) at N=1")
     ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream instead of a parallel graph branch")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3"],
                     help="student/projector GEMM arithmetic (teacher stays fp32 as in the reference); f32 = parity regime")
@@ -117,43 +197,8 @@ def main():
         torch.distributed.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
-    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
-
-    student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev)    # identical init on every rank
-    trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
-                        use_graph=not args.no_graph, precision=args.precision,
-                        overlap_teacher=not args.no_overlap)
-    images, caps = synthetic_batch(args.batch, VOCAB, T1, seed=1234, rank=rank)     # rank-specific shard of the global batch
     log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
-    log("models built; first step (hipGraph capture) ...")
-    trainer.train_step(images.to(dev), caps.to(dev))                                # inputs resident in HBM from here on
-    torch.cuda.synchronize()
-    log("captured; warm-up ...")
-    for _ in range(max(0, args.warmup - 1)):
-        trainer.train_step()
-    torch.cuda.synchronize()
-    log(f"timing {args.steps} steps ...")
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        trainer.train_step()
-    ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)                      # HIP events on the stream every kernel of the step runs on
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
-    loss = trainer.loss_dict()
+    ips, dt, dev_ms, loss = run_kd(args, args.precision, dev, rank, world, log)
     if rank == 0:
         ips = world * args.batch * args.steps / dt
         step_ms_dev = dev_ms / args.steps
@@ -177,9 +222,17 @@ def main():
                                  "(HIP events on the launch stream); denominator = fp32 MFMA peak for the exact-fp32 path, else the "
                                  "FLOP-weighted blend of the fp32 (teacher) and bf16 (student) MFMA peaks"},
         }
+        if world == 1 and not args.no_extras:
+            # secondary measurements, same process: the reference's mixed-precision regime and BASELINE configs[1]
+            if args.precision == "f32":
+                ips2, dt2, dev2, loss2 = run_kd(args, "bf16", dev, rank, world, log)
+                ach2 = GFLOP_PER_IMAGE * args.batch / (dev2 / args.steps)
+                out["mixed_precision"] = {"dtype": "bf16 student (fp32 accumulate, fp32 master weights) + f32 teacher",
+                                          "value": round(ips2, 2), "unit": "images/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                                          "final_loss": round(loss2["total_loss"], 5), "achieved_TFLOPs": round(ach2, 2),
+                                          "blended_peak_TFLOPs": round(mfma_peak("bf16"), 1)}
+            out["cfg2"] = run_cfg2(dev, log)
         if world == 1 and not args.no_cpu_baseline:
-            del trainer, student, teacher, projectors
-            torch.cuda.empty_cache()
             log(f"GPU: {ips:.1f} images/s; timing the CPU baseline on a bounded sample ...")
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
