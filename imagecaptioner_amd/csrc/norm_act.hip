@@ -51,6 +51,27 @@ __global__ void patchify16_kernel(const float* __restrict__ x, float* __restrict
   }
 }
 
+// conv weight [Cout][R][S][Cin] -> the layout its stride-1 data gradient reads as a FORWARD convolution over dY:
+// wt[ci][R-1-r][S-1-s][co] = w[co][r][s][ci]  (taps flipped, channels swapped).  One 32x32 (co x ci) tile per block
+// and tap, transposed through LDS so that both the read (along ci) and the write (along co) are 128-byte rows.
+__global__ void conv_weight_dgrad_layout_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int taps, int Cin) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((long)co * taps + tap) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  const int tflip = taps - 1 - tap;    // (R-1-r)*S + (S-1-s) = R*S-1 - (r*S+s)
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) wt[((long)ci * taps + tflip) * Cout + co] = tile[tx][r];
+  }
+}
+
 // ViT token assembly: x[b][0] = cls + pos[0]; x[b][1+p] = patch[b][p] + pos[1+p]
 __global__ void vit_assemble_kernel(const float* __restrict__ patch, const float* __restrict__ cls,
                                     const float* __restrict__ pos, float* __restrict__ x, int B, int Ntok, int D4) {
@@ -530,6 +551,13 @@ int ick_patchify16(const float* x, float* y, int B, int HW, void* stream) {
   const int G = HW / 16;
   ICK_LAUNCH(patchify16_kernel, dim3(grid_for((long)B * G * G * 192)), dim3(NT), 0, ST, x, y, B, HW, G);
   return ick::launch_status("patchify16");
+}
+
+int ick_conv_weight_dgrad_layout(const float* w, float* wt, int Cout, int R, int S, int Cin, void* stream) {
+  ICK_REQUIRE(w && wt && Cout > 0 && R > 0 && S > 0 && Cin > 0 && R * S <= 65535, "ick_conv_weight_dgrad_layout: bad arguments");
+  ICK_LAUNCH(conv_weight_dgrad_layout_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, R * S), dim3(NT), 0, ST, w, wt, Cout,
+             R * S, Cin);
+  return ick::launch_status("conv_weight_dgrad_layout");
 }
 
 int ick_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int Ntok, int D, void* stream) {

@@ -290,6 +290,7 @@ def attention_bwd(dO: torch.Tensor, P: torch.Tensor, q, qoff, qld, k, koff, kld,
 
 
 # ----------------------------------------------------------------------------- convolution (NHWC implicit GEMM)
+_DGRAD_AS_FWD = [True]     # A/B switch (tools): False = the CONV_DGRAD gather kernel for stride-1 data gradients too
 def conv_out_hw(H: int, W: int, R: int, S: int, stride: int, pad: int) -> Tuple[int, int]:
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
@@ -336,6 +337,17 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride
         gemm_raw(OP_CONV_DGRAD_S2, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), Nb * (H // 2) * (W // 2), Cin, K, 0, 0, Cin,
                  residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
                  conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+        return dx
+    if stride == 1 and _DGRAD_AS_FWD[0] and Cout % 32 == 0 and Cin % 4 == 0 and R - 1 - pad >= 0:
+        # stride-1 data gradient = forward convolution over dY with flipped, channel-swapped weights (one small
+        # transpose of the weight per call = per step): both GEMM operands are then k-contiguous, i.e. they take the
+        # LDS-DMA kernel's ds_read_b128 path instead of the strided [k][n] weight view
+        wt = empty(Cin, R, S, Cout, device=dy.device)
+        check(_lib.lib().ick_conv_weight_dgrad_layout(w.data_ptr(), wt.data_ptr(), Cout, R, S, Cin, _st()),
+              "ick_conv_weight_dgrad_layout")
+        gemm_raw(OP_CONV_FWD, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, K, K, Cin,
+                 residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
+                 conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad))
         return dx
     gemm_raw(OP_CONV_DGRAD, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, 0, 0, Cin,
              residual=_ptr(residual), ldr=Cin, accumulate=accumulate,

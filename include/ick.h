@@ -96,6 +96,7 @@ int ick_attention_fwd_d64(const float* q, int64_t qld, int64_t qbs, const float*
  * images arrive as the reference hands them over: (B,3,224,224) fp32 NCHW (train_student_kd.py:259). */
 int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stream);      /* -> (B,H,W,4), 4th channel 0 */
 int ick_patchify16(const float* x, float* y, int B, int HW, void* stream);                /* -> [B*(HW/16)^2][768], k=(c,py,px): timm PatchEmbed as a GEMM */
+int ick_conv_weight_dgrad_layout(const float* w, float* wt, int Cout, int R, int S, int Cin, void* stream); /* wt[ci][R-1-r][S-1-s][co] = w[co][r][s][ci]: with it the stride-1 data gradient of a convolution (autograd of student_model.py:57 through layer3/layer4) is a forward convolution over dY with pad R-1-pad, both GEMM operands k-contiguous */
 int ick_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int Ntok, int D, void* stream); /* cls token + pos_embed (timm forward_features) */
 
 /* ------------------------------------------------------------------ BatchNorm2d over NHWC rows [M = B*H*W][C]
