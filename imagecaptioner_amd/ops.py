@@ -52,7 +52,7 @@ def _load_tuned():
     MI355X); shapes not in the table use the library's wave-quantisation model."""
     import json
     import os
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles.json")
+    path = os.environ.get("ICK_TUNED_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles.json")
     if os.environ.get("ICK_NO_TUNED") == "1":      # A/B runs: the library's own tile model only
         return {}
     try:

@@ -95,11 +95,18 @@ class KDTrainer:
     def __init__(self, student, teacher, projectors: Dict[str, nn.Module], *, vocab_size: int, alpha=0.7, beta=0.2,
                  gamma=0.1, temperature=4.0, learning_rate=2e-4, weight_decay=0.01, max_norm=1.0, batches_per_epoch=1000,
                  batch_size: int = 64, t_plus_1: int = 16, use_graph: bool = True, process_group=None,
-                 precision: str = "f32", teacher_precision: str = "f32", overlap_teacher: bool = True):
+                 precision: str = "f32", teacher_precision: str = "f32", overlap_teacher: bool = True,
+                 accumulation_steps: int = 1):
         """precision: arithmetic of the student + projector contractions, forward and backward ("f32" exact, "bf16" =
         the reference's autocast regime :271-285 with fp32 master weights, "bf16x3" split-bf16); the teacher runs
         outside autocast in fp32 in the reference (:265-268) -> teacher_precision defaults to "f32"."""
         self.precision, self.teacher_precision = precision, teacher_precision
+        # gradient accumulation (reference :229,:285,:290): `loss / accumulation_steps` per micro-batch and one
+        # optimizer step per window.  Here the flat gradient buffer simply accumulates the un-divided gradients and
+        # 1/accumulation_steps is folded, with 1/world, into the fused clip+AdamW pass; the all-reduce and the LR
+        # schedule run on window boundaries only.
+        self.accumulation_steps = max(1, int(accumulation_steps))
+        self.micro_idx = 0
         self.side_stream = torch.cuda.Stream() if (overlap_teacher and torch.cuda.is_available()) else None
         self.student, self.teacher, self.projectors = student, teacher, projectors
         self.device = next(student.parameters()).device
@@ -137,8 +144,9 @@ class KDTrainer:
     # ------------------------------------------------------------------ the step body
     def _forward_backward(self):
         """teacher fwd (no grad, fp32) -> student fwd -> projector -> KD loss -> backward  (reference :262-288)."""
-        self.flat.grad.zero_()
-        self.drop_step += 1
+        if self.accumulation_steps == 1:
+            self.flat.grad.zero_()   # gradients stay inspectable after the step; with accumulation the buffer is
+        self.drop_step += 1          # zeroed at the end of the optimizer pass instead, so a window accumulates
         cin, ctg = self.captions[:-1], self.captions[1:]
         # The frozen teacher's forward does not depend on the student: it runs on a side HIP stream (a parallel
         # branch of the captured graph), so its large GEMMs fill the CUs that the student's latency-bound
@@ -170,7 +178,7 @@ class KDTrainer:
         """clip_grad_norm_(student, 1.0); clip per projector; AdamW (reference :292-299), fused over the flat buffers.
         Gradients hold the SUM over ranks at this point; 1/world is folded into the kernels."""
         f = self.flat
-        inv = 1.0 / self.world
+        inv = 1.0 / (self.world * self.accumulation_steps)
         a0, _ = f.segment("encoder")
         _, b2 = f.segment("refine")
         pa, pb = f.segment("projector")
@@ -184,6 +192,8 @@ class KDTrainer:
             norm = self.norms[1:2] if name == "projector" else self.norms[0:1]
             ops.adamw_step(f.param[a:b], f.grad[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], 0.0, self.betas, self.eps, self.wd, 0,
                            norm=norm, max_norm=self.max_norm, inv_scale=inv, hyper=self.hyper[gi])
+        if self.accumulation_steps > 1:
+            f.grad.zero_()                               # optimizer.zero_grad() (reference :299)
 
     def _update_hyper(self):
         t = self.step_count + 1
@@ -244,20 +254,24 @@ class KDTrainer:
         self.student.train()
         if self.use_graph and self.g_fb is None:
             self._capture()
-        self._update_hyper()
+        boundary = (self.micro_idx + 1) % self.accumulation_steps == 0
+        if boundary:
+            self._update_hyper()
         if self.use_graph:
             self.g_fb.replay()
         else:
             self._forward_backward()
-        if self.world > 1:
-            dp.allreduce_gradients(self.flat.grad, self.pg)
-        if self.use_graph:
-            self.g_opt.replay()
-        else:
-            self._optimizer()
-        self.step_count += 1
+        self.micro_idx += 1
         self.batch_idx += 1
-        self._f_now = self._f_next
+        if boundary:
+            if self.world > 1:
+                dp.allreduce_gradients(self.flat.grad, self.pg)
+            if self.use_graph:
+                self.g_opt.replay()
+            else:
+                self._optimizer()
+            self.step_count += 1
+            self._f_now = self._f_next
         if self.batch_idx >= self.batches_per_epoch:
             self.batch_idx = 0
             self.epoch += 1

@@ -210,3 +210,32 @@ def test_mixed_precision_student_vs_fp32_path(prec, tol_logit, tol_loss, tol_gra
         ga = out[prec][1][k]
         assert ((ga - gb).norm() / gb.norm()).item() < tol_grad, k
         assert (torch.dot(ga, gb) / (ga.norm() * gb.norm())).item() >= 0.93, k
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_gradient_accumulation_window_equals_one_step(use_graph):
+    """accumulation_steps=2 (reference train_student_kd.py:229,:285-299): two micro-steps on the SAME batch accumulate
+    2g, the window's optimizer step divides by 2 -> the parameters must equal those of a 1-step trainer on that batch
+    (dropout off; train-mode BatchNorm uses batch statistics, so the doubled running-stat update does not matter)."""
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    images, caps = synthetic_batch(2, 5000, 16, seed=3)
+    params = {}
+    for acc in (1, 2):
+        s, t, p = build_kd_models(device="cuda")
+        _no_dropout(s, p)
+        tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=2, use_graph=use_graph, accumulation_steps=acc)
+        before = tr.flat.param.clone()
+        for _ in range(acc):
+            tr.train_step(images.cuda(), caps.cuda())
+        assert tr.step_count == 1
+        params[acc] = (tr.flat.param.clone(), before)
+        del tr, s, t, p
+        torch.cuda.empty_cache()
+    delta1 = params[1][0] - params[1][1]
+    delta2 = params[2][0] - params[2][1]
+    assert float(delta1.abs().max()) > 0
+    # Adam's first step is lr * g / (|g| + eps): elements whose gradient is ~eps amplify the fp32 reordering noise of
+    # the second micro-step (split-K atomics), hence a max-norm bound of 5 % of the step and a tight bound on the mean
+    assert float((delta1 - delta2).abs().max()) <= 5e-2 * float(delta1.abs().max())
+    assert float((delta1 - delta2).abs().mean()) <= 1e-3 * float(delta1.abs().mean())
