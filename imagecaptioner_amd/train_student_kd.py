@@ -222,10 +222,11 @@ class KDTrainer:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
+        # thread_local: under torch.distributed the RCCL watchdog thread polls events while this thread captures
+        with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
             self._forward_backward()
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
+        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self._optimizer()
         with torch.no_grad():
             for b, saved in bufs:
