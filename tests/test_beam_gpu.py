@@ -85,3 +85,34 @@ def test_caption_image_api_errors(teacher):
         stoi, itos = {"<END>": 2}, {2: "<END>"}
     with pytest.raises(AssertionError):
         teacher.caption_image(torch.zeros(3, 224, 224), NoStart())
+
+
+def test_student_evaluator_on_synthetic_loader(teacher):
+    """StudentEvaluator.compare_models_on_dataset (reference evaluate_student.py:99-201) over a synthetic loader: the
+    batched student decode must give, per image, exactly the caption of the reference-style B=1 caption_image, and the
+    result dict has the reference's layout."""
+    from imagecaptioner_amd.evaluate_student import StudentEvaluator
+    from imagecaptioner_amd.student_model import CaptioningStudent
+    from imagecaptioner_amd.utils.seeded_init import apply_seeded_init, synthetic_batch
+    vocab = Vocab(5000)
+    student = apply_seeded_init(CaptioningStudent(5000, 256, 512, 2), 7).cuda().eval()
+    with torch.no_grad():   # margins large enough for tie-free argmax (see test_configs_gpu.py)
+        student.decoder.output_projection[3].weight.mul_(16.0)
+        student.decoder.embedding.weight.mul_(10.0)
+    ev = StudentEvaluator(student, teacher, vocab, "cuda")
+    loader = [synthetic_batch(4, 5000, 16, seed=300 + i) for i in range(2)]
+    res = ev.compare_models_on_dataset(loader, num_samples=5, per_batch=3)
+    assert res["total_samples"] == 5 and len(res["reference_captions"]) == 5
+    for side in ("student", "teacher"):
+        assert set(res[side]) == {"bleu1_scores", "bleu2_scores", "meteor_scores", "generated_captions", "inference_times",
+                                  "successful_generations"}
+        assert len(res[side]["generated_captions"]) == 5
+        assert len(res[side]["bleu1_scores"]) == res[side]["successful_generations"]
+        assert all(0.0 <= v <= 1.0 for v in res[side]["bleu1_scores"] + res[side]["meteor_scores"])
+    imgs = loader[0][0]
+    for j in range(3):
+        single = " ".join(student.caption_image(imgs[j], vocab, max_length=25)).strip()
+        batched = res["student"]["generated_captions"][j]
+        assert batched in (single, "")          # "" only if the reference's "> 2 words" filter dropped it
+        if len(single.split()) > 2:
+            assert batched == single
