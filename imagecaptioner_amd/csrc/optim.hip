@@ -51,8 +51,12 @@ __global__ void norm_finalize_kernel(const float* __restrict__ partial, int n, f
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
                              const float* __restrict__ norm, float max_norm, float inv_scale, int write_clipped,
-                             const float* __restrict__ hyper) {
+                             const float* __restrict__ hyper, const float* __restrict__ scaler) {
   if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }  // device-resident schedule (hipGraph replay)
+  if (scaler) {   // dynamic loss scaling (torch.amp.GradScaler semantics): scaler = {scale, 1/scale, found_inf}
+    if (scaler[2] != 0.f) return;                                 // scaler.step(): skip the update on inf / nan gradients
+    inv_scale *= scaler[1];                                       // scaler.unscale_()
+  }
   float coef = inv_scale;
   if (norm) { const float c = max_norm / (norm[0] * inv_scale + 1e-6f); coef *= (c < 1.f ? c : 1.f); }
   const float step = lr / bc1, isb2 = rsqrtf(bc2), decay = 1.f - lr * wd;
@@ -63,6 +67,25 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
     m[i] = mm; v[i] = vv;
     p[i] = p[i] * decay - step * mm / (sqrtf(vv) * isb2 + eps);
     if (write_clipped) g[i] = gg;
+  }
+}
+
+// GradScaler bookkeeping on device (so a captured graph carries it): st = {scale, 1/scale, found_inf, good_steps}.
+// check: found_inf = any of the n_norms gradient norms (of the SCALED gradients) is inf / nan       (scaler.unscale_)
+// update: found_inf ? scale *= backoff, good_steps = 0 : (++good_steps == interval ? scale *= growth, good_steps = 0)
+__global__ void loss_scale_check_kernel(const float* __restrict__ norms, int n_norms, float* __restrict__ st) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    bool bad = false;
+    for (int i = 0; i < n_norms; ++i) bad = bad || !isfinite(norms[i]);
+    st[2] = bad ? 1.f : 0.f;
+  }
+}
+__global__ void loss_scale_update_kernel(float* __restrict__ st, float growth, float backoff, int interval) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float scale = st[0], good = st[3];
+    if (st[2] != 0.f) { scale *= backoff; good = 0.f; }
+    else if (++good >= (float)interval) { scale *= growth; good = 0.f; }
+    st[0] = scale; st[1] = 1.f / scale; st[3] = good;
   }
 }
 
@@ -84,13 +107,26 @@ int ick_grad_norm(const float* x, int64_t n, float* workspace, float* norm_out, 
 
 int ick_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, const float* norm, float max_norm, float inv_scale, int write_clipped,
-                   const float* hyper, void* stream) {
+                   const float* hyper, const float* scaler, void* stream) {
   ICK_REQUIRE(p && g && m && v && n > 0 && (step >= 1 || hyper), "ick_adamw_step: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   long gr = (n + NT - 1) / NT; if (gr > 4096) gr = 4096;
   ICK_LAUNCH(adamw_kernel, dim3((int)gr), dim3(NT), 0, ST, p, g, m, v, (long)n, lr, beta1, beta2, eps, weight_decay,
-                     bc1, bc2, norm, max_norm, inv_scale, write_clipped, hyper);
+                     bc1, bc2, norm, max_norm, inv_scale, write_clipped, hyper, scaler);
   return ick::launch_status("adamw_step");
+}
+
+int ick_loss_scale_check(const float* norms, int n_norms, float* state, void* stream) {
+  ICK_REQUIRE(norms && state && n_norms > 0, "ick_loss_scale_check: bad arguments");
+  ICK_LAUNCH(loss_scale_check_kernel, dim3(1), dim3(64), 0, ST, norms, n_norms, state);
+  return ick::launch_status("loss_scale_check");
+}
+
+int ick_loss_scale_update(float* state, float growth_factor, float backoff_factor, int growth_interval, void* stream) {
+  ICK_REQUIRE(state && growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0,
+              "ick_loss_scale_update: bad arguments");
+  ICK_LAUNCH(loss_scale_update_kernel, dim3(1), dim3(64), 0, ST, state, growth_factor, backoff_factor, growth_interval);
+  return ick::launch_status("loss_scale_update");
 }
 
 }  // extern "C"

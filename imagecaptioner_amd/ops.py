@@ -602,7 +602,16 @@ def grad_norm(flat: torch.Tensor, workspace: torch.Tensor, norm_out: torch.Tenso
 
 
 def adamw_step(p, g, m, v, lr, betas, eps, wd, step, norm=None, max_norm=1.0, inv_scale=1.0, write_clipped=False,
-               hyper=None):
+               hyper=None, scaler=None):
     check(_lib.lib().ick_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1],
-                                    eps, wd, step, _ptr(norm), max_norm, inv_scale, int(write_clipped), _ptr(hyper), _st()),
-          "ick_adamw_step")
+                                    eps, wd, step, _ptr(norm), max_norm, inv_scale, int(write_clipped), _ptr(hyper),
+                                    _ptr(scaler), _st()), "ick_adamw_step")
+
+
+def loss_scale_check(norms: torch.Tensor, state: torch.Tensor) -> None:
+    check(_lib.lib().ick_loss_scale_check(norms.data_ptr(), norms.numel(), state.data_ptr(), _st()), "ick_loss_scale_check")
+
+
+def loss_scale_update(state: torch.Tensor, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000) -> None:
+    check(_lib.lib().ick_loss_scale_update(state.data_ptr(), growth_factor, backoff_factor, growth_interval, _st()),
+          "ick_loss_scale_update")

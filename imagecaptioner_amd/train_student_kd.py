@@ -96,7 +96,7 @@ class KDTrainer:
                  gamma=0.1, temperature=4.0, learning_rate=2e-4, weight_decay=0.01, max_norm=1.0, batches_per_epoch=1000,
                  batch_size: int = 64, t_plus_1: int = 16, use_graph: bool = True, process_group=None,
                  precision: str = "f32", teacher_precision: str = "f32", overlap_teacher: bool = True,
-                 accumulation_steps: int = 1):
+                 accumulation_steps: int = 1, loss_scale=None, growth_interval: int = 2000):
         """precision: arithmetic of the student + projector contractions, forward and backward ("f32" exact, "bf16" =
         the reference's autocast regime :271-285 with fp32 master weights, "bf16x3" split-bf16); the teacher runs
         outside autocast in fp32 in the reference (:265-268) -> teacher_precision defaults to "f32"."""
@@ -107,6 +107,10 @@ class KDTrainer:
         # schedule run on window boundaries only.
         self.accumulation_steps = max(1, int(accumulation_steps))
         self.micro_idx = 0
+        # loss_scale: None = no scaling (fp32 / bf16 need none); a float = GradScaler(init_scale=that) with the torch
+        # defaults growth 2.0 / backoff 0.5 / growth_interval (reference :239,:288-298).  The state lives on the device
+        # ({scale, 1/scale, found_inf, good_steps}) so the captured graphs carry scale(), unscale_(), step(), update().
+        self.loss_scale0, self.growth_interval = loss_scale, int(growth_interval)
         self.side_stream = torch.cuda.Stream() if (overlap_teacher and torch.cuda.is_available()) else None
         self.student, self.teacher, self.projectors = student, teacher, projectors
         self.device = next(student.parameters()).device
@@ -136,6 +140,11 @@ class KDTrainer:
         ops.set_dropout_step_counter(self.drop_step)
         self.images = torch.zeros(batch_size, 3, 224, 224, dtype=torch.float32, device=self.device)
         self.captions = torch.zeros(t_plus_1, batch_size, dtype=torch.int64, device=self.device)
+        self.scaler = None
+        if self.loss_scale0 is not None:
+            s0 = float(self.loss_scale0)
+            self.scaler = torch.tensor([s0, 1.0 / s0, 0.0, 0.0], dtype=torch.float32, device=self.device)
+            self.loss.unit_grad_fastpath = False          # the seed gradient of total_loss is the device-resident scale
         self.out5 = None
         self.use_graph = use_graph and self.device.type == "cuda"
         self.g_fb: Optional[torch.cuda.CUDAGraph] = None
@@ -170,7 +179,10 @@ class KDTrainer:
             s_out = {"logits": logits, "encoder_features": enc, "hidden_states": hids}
             t_out["encoder_features"] = self.projectors["encoder"](t_out["encoder_features"])
             out5 = self.loss.forward_device(s_out, t_out, ctg)
-            out5[0].backward()
+            if self.scaler is None:
+                out5[0].backward()
+            else:
+                out5[0].backward(self.scaler[0])          # scaler.scale(loss).backward()
         self.out5 = out5
         return out5
 
@@ -185,13 +197,17 @@ class KDTrainer:
         ops.grad_norm(f.grad[a0:b2], self.ws, self.norms[0:1])
         if pb > pa:
             ops.grad_norm(f.grad[pa:pb], self.ws, self.norms[1:2])
+        if self.scaler is not None:
+            ops.loss_scale_check(self.norms, self.scaler)
         for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
             a, b = f.segment(name)
             if b <= a:
                 continue
             norm = self.norms[1:2] if name == "projector" else self.norms[0:1]
             ops.adamw_step(f.param[a:b], f.grad[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], 0.0, self.betas, self.eps, self.wd, 0,
-                           norm=norm, max_norm=self.max_norm, inv_scale=inv, hyper=self.hyper[gi])
+                           norm=norm, max_norm=self.max_norm, inv_scale=inv, hyper=self.hyper[gi], scaler=self.scaler)
+        if self.scaler is not None:
+            ops.loss_scale_update(self.scaler, 2.0, 0.5, self.growth_interval)
         if self.accumulation_steps > 1:
             f.grad.zero_()                               # optimizer.zero_grad() (reference :299)
 
@@ -213,6 +229,8 @@ class KDTrainer:
 
     def _capture(self):
         bufs = [(b, b.clone()) for b in self.student.buffers()]       # warm-up must not count as training steps
+        if self.scaler is not None:
+            bufs.append((self.scaler, self.scaler.clone()))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):

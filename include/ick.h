@@ -174,7 +174,12 @@ int ick_scale_by_scalar(float* x, const float* scalar, int64_t n, void* stream);
 int ick_grad_norm(const float* x, int64_t n, float* workspace, float* norm_out, int accumulate, void* stream);
 int ick_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, const float* norm, float max_norm, float inv_scale, int write_clipped,
-                   const float* hyper, void* stream);
+                   const float* hyper, const float* scaler, void* stream);
+/* torch.amp.GradScaler (train_student_kd.py:239,288-298) as device state {scale, 1/scale, found_inf, good_steps}:
+ * _check marks found_inf from the norms of the scaled gradients (unscale_), ick_adamw_step(scaler=state) unscales and
+ * skips on found_inf (scaler.step), _update applies growth / backoff (scaler.update). */
+int ick_loss_scale_check(const float* norms, int n_norms, float* state, void* stream);
+int ick_loss_scale_update(float* state, float growth_factor, float backoff_factor, int growth_interval, void* stream);
 
 #ifdef __cplusplus
 }

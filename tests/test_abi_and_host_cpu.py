@@ -45,7 +45,7 @@ def test_argument_validation_needs_no_gpu():
     assert L.ick_token_kd_ce(16, 16, None, 16, 16, 16, 16, 4, 30000, 4.0, 1.0, 0.0, None) < 0
     assert b"too large" in L.ick_last_error()
     with pytest.raises(_lib.IckError):
-        _lib.check(L.ick_adamw_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 0.0, 1, None, 1.0, 1.0, 0, None, None))
+        _lib.check(L.ick_adamw_step(None, None, None, None, 0, 0.0, 0.9, 0.999, 1e-8, 0.0, 1, None, 1.0, 1.0, 0, None, None, None))
 
 
 def test_gemm_struct_layout_matches_header():

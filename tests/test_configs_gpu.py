@@ -239,3 +239,37 @@ def test_gradient_accumulation_window_equals_one_step(use_graph):
     # the second micro-step (split-K atomics), hence a max-norm bound of 5 % of the step and a tight bound on the mean
     assert float((delta1 - delta2).abs().max()) <= 5e-2 * float(delta1.abs().max())
     assert float((delta1 - delta2).abs().mean()) <= 1e-3 * float(delta1.abs().mean())
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_device_side_grad_scaler(use_graph):
+    """KDTrainer(loss_scale=...) = torch.amp.GradScaler around the step (reference train_student_kd.py:239,288-298) with
+    its state on the device: (a) a finite scale changes nothing (gradients are scaled then unscaled), (b) the scale
+    grows by 2 after `growth_interval` good steps, (c) overflowing gradients skip the update and halve the scale."""
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    images, caps = synthetic_batch(2, 5000, 16, seed=3)
+    deltas = {}
+    for scale in (None, 1024.0, 3.0e38):
+        s, t, p = build_kd_models(device="cuda")
+        _no_dropout(s, p)
+        tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=2, use_graph=use_graph, loss_scale=scale, growth_interval=2)
+        before = tr.flat.param.clone()
+        tr.train_step(images.cuda(), caps.cuda())
+        deltas[scale] = tr.flat.param.clone() - before
+        if scale == 1024.0:
+            assert tr.scaler.tolist() == [1024.0, 1.0 / 1024.0, 0.0, 1.0]
+            tr.train_step()
+            assert tr.scaler.tolist() == [2048.0, 1.0 / 2048.0, 0.0, 0.0]          # grew after 2 good steps
+            assert abs(tr.loss_dict()["total_loss"]) < 1e3                        # the reported loss is never scaled
+        if scale == 3.0e38:
+            st = tr.scaler.tolist()
+            assert st[2] == 1.0 and st[0] == pytest.approx(1.5e38, rel=1e-6) and st[3] == 0.0   # overflow: backoff
+            assert float(deltas[scale].abs().max()) == 0.0                        # and the update was skipped
+            assert float(tr.flat.exp_avg.abs().max()) == 0.0
+        del tr, s, t, p
+        torch.cuda.empty_cache()
+    d0, d1 = deltas[None], deltas[1024.0]
+    assert float(d0.abs().max()) > 0
+    assert float((d0 - d1).abs().max()) <= 5e-2 * float(d0.abs().max())
+    assert float((d0 - d1).abs().mean()) <= 1e-3 * float(d0.abs().mean())
