@@ -133,6 +133,33 @@ def run_kd(args, precision, dev, rank, world, log):
     return world * args.batch * args.steps / dt, dt, dev_ms, loss
 
 
+def dominant_kernel(dev, iters=20):
+    """The single largest kernel of the step in isolation: the teacher ViT's fc1 Linear (12 launches per step,
+    igemm_f32_glds_kernel<NT,64,64>, M = 64 x 197 tokens, N = 1536, K = 384, bias + GELU fused), timed with HIP events
+    around `iters` back-to-back launches on the launch stream.  Algorithmic FLOPs = 2 M N K."""
+    from imagecaptioner_amd import ops
+    from imagecaptioner_amd._lib import ACT_GELU
+    M, N, K = BATCH * 197, 1536, 384
+    x = torch.randn(M, K, device=dev)
+    w = torch.randn(N, K, device=dev) * 0.05
+    b = torch.randn(N, device=dev)
+    y = torch.empty(M, N, device=dev)
+    for _ in range(3):
+        ops.linear_fwd(x, w, b, act=ACT_GELU, out=y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.linear_fwd(x, w, b, act=ACT_GELU, out=y)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    tf = 2.0 * M * N * K / us / 1e6
+    return {"kernel": "igemm_f32_glds_kernel<NT,64,64> ViT fc1 Linear+GELU 12608x1536x384 (fp32 MFMA, LDS-DMA staging)",
+            "avg_us": round(us, 1), "achieved": round(tf, 1), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_F32_MFMA_TF, 4)}
+
+
 def run_cfg2(dev, log, batch=128, max_length=20, iters=10):
     """BASELINE.json configs[1]: student ResNet50+LSTM (256/512/2-layer) forward + batched greedy decode in bf16 at
     batch 128 on one GPU (captured once into a hipGraph, no per-token host sync).  8.87 algorithmic GFLOP/image
@@ -223,6 +250,7 @@ def main():
                                  "FLOP-weighted blend of the fp32 (teacher) and bf16 (student) MFMA peaks"},
         }
         if world == 1 and not args.no_extras:
+            out["roofline"]["dominant_kernel"] = dominant_kernel(dev)
             # secondary measurements, same process: the reference's mixed-precision regime and BASELINE configs[1]
             if args.precision == "f32":
                 ips2, dt2, dev2, loss2 = run_kd(args, "bf16", dev, rank, world, log)
