@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
     if (NBUF == 3 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#if ICK_ABL >= 3
+#if ICK_ABL == 3
     if (kt + NBUF - 1 < nkt && p.alpha == 12345.f) issue(kt + NBUF - 1, cb == 0 ? NBUF - 1 : cb - 1);
 #else
     if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1, cb == 0 ? NBUF - 1 : cb - 1);
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mb + (r & 3) + 8 * (r >> 2);
-          if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || alpha == 12345.f)) {
+          if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL == 4 || alpha == 12345.f)) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq += v * v;
             v = act_fn(v + bias, act);
@@ -360,12 +360,16 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
           }
         }
       }
-      if (p.stat_sum && (ICK_ABL < 1 || alpha == 12345.f)) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
+      if (p.stat_sum && (ICK_ABL < 1 || ICK_ABL == 4 || alpha == 12345.f)) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
         ssum += __shfl_xor(ssum, 32);
         ssq += __shfl_xor(ssq, 32);
         if (lane < 32 && nok) {
           const long so = (long)(tile_m % p.stat_copies) * p.stat_stride + n;   // copy of this row tile
+#if ICK_ABL == 4   // timing experiment only: fp32 atomics instead of fp64
+          atomicAdd(reinterpret_cast<float*>(p.stat_sum) + so, ssum); atomicAdd(reinterpret_cast<float*>(p.stat_sq) + so, ssq);
+#else
           atomicAdd(p.stat_sum + so, (double)ssum); atomicAdd(p.stat_sq + so, (double)ssq);
+#endif
         }
       }
     }
