@@ -242,6 +242,126 @@ __global__ void kd_combine_kernel(const float* __restrict__ row_kl, const float*
   }
 }
 
+// ------------------------------------------------------------------ OptimizedDistillationLoss
+// reference: /root/reference/src/train_student_kd_optimized.py:34-128.  Same row-in-LDS structure as token_kd_ce_kernel:
+//   row_kd[r]   = -sum_v p_t log p_s            (soft-target cross entropy at temperature tau; the reduce applies tau^2/rows)
+//   row_hard[r] = focal_alpha (1 - p)^focal_gamma ce,  ce = -log softmax(s)[target], p = exp(-ce)   (every row: no ignore_index)
+//   ds[r][v]    = g_kd (p_s - p_t) + g_hard focal'(ce) (softmax(s)[v] - [v == target])
+// with g_kd = grad_scale * alpha_now * tau / rows, g_hard = grad_scale * (1 - alpha_now) / rows and
+// focal'(ce) = focal_alpha [(1-p)^gamma + gamma (1-p)^(gamma-1) p ce].
+__global__ __launch_bounds__(NT) void token_softce_focal_kernel(const float* __restrict__ s, const float* __restrict__ t,
+                                                               const long* __restrict__ targets, float* __restrict__ ds,
+                                                               float* __restrict__ row_kd, float* __restrict__ row_hard,
+                                                               int V, float inv_tau, float g_kd, float g_hard,
+                                                               float focal_alpha, float focal_gamma) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  float* ss = sh;
+  float* ts = sh + V;
+  float* red = sh + 2 * V;
+  const long r = blockIdx.x;
+  const float* sr = s + r * V;
+  const float* tr = t + r * V;
+  const int tid = threadIdx.x;
+  float ms = -INFINITY, mt = -INFINITY;
+  for (int i = tid; i < V; i += NT) {
+    const float a = sr[i], b = tr[i];
+    ss[i] = a; ts[i] = b; ms = fmaxf(ms, a); mt = fmaxf(mt, b);
+  }
+  ms = block_max(ms, red);
+  mt = block_max(mt, red);
+  float zs = 0.f, zt = 0.f, z1 = 0.f;
+  for (int i = tid; i < V; i += NT) {
+    zs += expf((ss[i] - ms) * inv_tau);
+    zt += expf((ts[i] - mt) * inv_tau);
+    z1 += expf(ss[i] - ms);
+  }
+  zs = block_sum(zs, red);
+  zt = block_sum(zt, red);
+  z1 = block_sum(z1, red);
+  const float lzs = logf(zs), lz1 = logf(z1);
+  const long tgt = targets[r];
+  const float ce = -((ss[tgt] - ms) - lz1);
+  const float p = expf(-ce), om = fmaxf(1.f - p, 0.f);
+  const float pw = powf(om, focal_gamma);
+  const float dfocal = focal_alpha * (pw + (om > 0.f ? focal_gamma * powf(om, focal_gamma - 1.f) * p * ce : 0.f));
+  const float gh = g_hard * dfocal;
+  const float izs = 1.f / zs, izt = 1.f / zt, iz1 = 1.f / z1;
+  float kd = 0.f;
+  float* dr = ds + r * V;
+  for (int i = tid; i < V; i += NT) {
+    const float a = (ss[i] - ms) * inv_tau;
+    const float ps = expf(a) * izs, pt = expf((ts[i] - mt) * inv_tau) * izt;
+    kd -= pt * (a - lzs);
+    dr[i] = g_kd * (ps - pt) + gh * (expf(ss[i] - ms) * iz1 - (i == tgt ? 1.f : 0.f));
+  }
+  kd = block_sum(kd, red);
+  if (tid == 0) { row_kd[r] = kd; row_hard[r] = focal_alpha * pw * ce; }
+}
+
+// per-token cosine feature loss (:84-94): one wave per token row; cos = <s,t> / (max(|s|,eps) max(|t|,eps)), eps = 1e-12
+// (F.normalize).  part[row] = cos; ds, dt (either may be NULL) = -gscale/rows * d cos.
+__global__ __launch_bounds__(NT) void feature_cosine_kernel(const float* __restrict__ s, const float* __restrict__ t,
+                                                           float* __restrict__ ds, float* __restrict__ dt,
+                                                           float* __restrict__ part, long rows, int E, float g) {
+  const int lane = threadIdx.x & 63;
+  const long row = blockIdx.x * (long)(NT / 64) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* a = s + row * E;
+  const float* b = t + row * E;
+  float saa = 0.f, sbb = 0.f, sab = 0.f;
+  for (int e = lane; e < E; e += 64) { const float x = a[e], y = b[e]; saa += x * x; sbb += y * y; sab += x * y; }
+  saa = wave_sum(saa); sbb = wave_sum(sbb); sab = wave_sum(sab);
+  const float na = fmaxf(sqrtf(saa), 1e-12f), nb = fmaxf(sqrtf(sbb), 1e-12f);
+  const float cosv = sab / (na * nb);
+  if (lane == 0) part[row] = cosv;
+  // d cos / d a = b / (na nb) - cos a / na^2   (for |a| > eps)
+  const float ia = 1.f / na, ib = 1.f / nb;
+  for (int e = lane; e < E; e += 64) {
+    const float x = a[e], y = b[e];
+    if (ds) ds[row * E + e] = -g * (y * ia * ib - cosv * x * ia * ia);
+    if (dt) dt[row * E + e] = -g * (x * ia * ib - cosv * y * ib * ib);
+  }
+}
+
+// hidden term (:101-110): MSE over (B,H) of the attention-weighted time sums; w (T,B) already softmaxed over time.
+// one workgroup per batch row b: part[b] = sum_h (ws - wt)^2 ; ds[t][b][h] = g * 2 (ws - wt) w[t][b] / (B H)
+__global__ __launch_bounds__(NT) void weighted_hidden_mse_kernel(const float* __restrict__ s, const float* __restrict__ t,
+                                                                const float* __restrict__ w, float* __restrict__ ds,
+                                                                float* __restrict__ part, int T, int B, int H, float g) {
+  __shared__ float red[NT / 64];
+  const int b = blockIdx.x;
+  float acc = 0.f;
+  for (int h = threadIdx.x; h < H; h += NT) {
+    float d = 0.f;
+    for (int k = 0; k < T; ++k) d += w[k * B + b] * (s[((long)k * B + b) * H + h] - t[((long)k * B + b) * H + h]);
+    acc += d * d;
+    if (ds) for (int k = 0; k < T; ++k) ds[((long)k * B + b) * H + h] = g * 2.f * d * w[k * B + b] / ((float)B * H);
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part[b] = acc;
+}
+
+// out7 = {total, token, feature, hidden, kd, hard, hard} (the reference's dict order :120-128), deterministic reduce
+__global__ void optloss_combine_kernel(const float* __restrict__ row_kd, const float* __restrict__ row_hard, int rows,
+                                       const float* __restrict__ cos_part, long cos_rows, const float* __restrict__ hid_part,
+                                       int hid_B, int hid_H, float alpha_now, float beta_now, float gamma_now, float tau,
+                                       float* __restrict__ out) {
+  __shared__ float red[NT / 64];
+  float kd = 0.f, hd = 0.f, cs = 0.f, hm = 0.f;
+  for (int i = threadIdx.x; i < rows; i += NT) { kd += row_kd[i]; hd += row_hard[i]; }
+  if (cos_part) for (long i = threadIdx.x; i < cos_rows; i += NT) cs += cos_part[i];
+  if (hid_part) for (int i = threadIdx.x; i < hid_B; i += NT) hm += hid_part[i];
+  kd = block_sum(kd, red); hd = block_sum(hd, red); cs = block_sum(cs, red); hm = block_sum(hm, red);
+  if (threadIdx.x == 0) {
+    const float kdl = kd / rows * tau * tau, hard = hd / rows;
+    const float token = alpha_now * kdl + (1.f - alpha_now) * hard;
+    const float feat = cos_part ? 1.f - cs / (float)cos_rows : 0.f;
+    const float hid = hid_part ? hm / ((float)hid_B * hid_H) : 0.f;
+    out[0] = token + beta_now * feat + gamma_now * hid;
+    out[1] = token; out[2] = feat; out[3] = hid; out[4] = kdl; out[5] = hard; out[6] = hard;
+  }
+}
+
 // x[i] *= *scalar (device scalar) — applies autograd's incoming grad_output to a precomputed gradient
 __global__ void scale_by_scalar_kernel(float* __restrict__ x, const float* __restrict__ sc, long n) {
   const float k = *sc;
@@ -297,6 +417,45 @@ int ick_kd_combine(const float* row_kl, const float* row_ce, int rows, const int
   ICK_LAUNCH(kd_combine_kernel, dim3(1), dim3(NT), 0, ST, row_kl, row_ce, rows, n_valid, feat_part, Bf, Ef, hid_part,
                      hid_steps * hid_B, hid_B, hid_H, hid_steps > 0 ? hid_steps : 1, w_ce, alpha, beta, gamma, tau, out5);
   return ick::launch_status("kd_combine");
+}
+
+int ick_token_softce_focal(const float* s, const float* t, const int64_t* targets, float* ds, float* row_kd, float* row_hard,
+                           int rows, int V, float tau, float g_kd, float g_hard, float focal_alpha, float focal_gamma,
+                           void* stream) {
+  ICK_REQUIRE(s && t && targets && ds && row_kd && row_hard && rows > 0 && V > 0 && tau > 0, "ick_token_softce_focal: bad arguments");
+  const size_t sh = ((size_t)2 * V + 8) * sizeof(float);
+  ICK_REQUIRE(sh <= 160 * 1024, "ick_token_softce_focal: vocabulary %d too large for the LDS-staged row", V);
+  if (sh > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(token_softce_focal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (e != hipSuccess) return ick::fail((int)e, "ick_token_softce_focal: cannot raise dynamic LDS to %zu", sh);
+  }
+  ICK_LAUNCH(token_softce_focal_kernel, dim3(rows), dim3(NT), sh, ST, s, t, (const long*)targets, ds, row_kd, row_hard, V,
+             1.0f / tau, g_kd, g_hard, focal_alpha, focal_gamma);
+  return ick::launch_status("token_softce_focal");
+}
+
+int ick_feature_cosine(const float* s, const float* t, float* ds, float* dt, float* part, int64_t rows, int E, float gscale,
+                       void* stream) {
+  ICK_REQUIRE(s && t && part && rows > 0 && E > 0, "ick_feature_cosine: bad arguments");
+  ICK_LAUNCH(feature_cosine_kernel, dim3((int)((rows + NT / 64 - 1) / (NT / 64))), dim3(NT), 0, ST, s, t, ds, dt, part, (long)rows, E,
+             gscale / (float)rows);
+  return ick::launch_status("feature_cosine");
+}
+
+int ick_weighted_hidden_mse(const float* s, const float* t, const float* w, float* ds, float* part, int T, int B, int H,
+                            float gscale, void* stream) {
+  ICK_REQUIRE(s && t && w && part && T > 0 && B > 0 && H > 0, "ick_weighted_hidden_mse: bad arguments");
+  ICK_LAUNCH(weighted_hidden_mse_kernel, dim3(B), dim3(NT), 0, ST, s, t, w, ds, part, T, B, H, gscale);
+  return ick::launch_status("weighted_hidden_mse");
+}
+
+int ick_optloss_combine(const float* row_kd, const float* row_hard, int rows, const float* cos_part, int64_t cos_rows,
+                        const float* hid_part, int hid_B, int hid_H, float alpha_now, float beta_now, float gamma_now,
+                        float tau, float* out7, void* stream) {
+  ICK_REQUIRE(row_kd && row_hard && out7 && rows > 0, "ick_optloss_combine: bad arguments");
+  ICK_LAUNCH(optloss_combine_kernel, dim3(1), dim3(NT), 0, ST, row_kd, row_hard, rows, cos_part, (long)cos_rows, hid_part,
+             hid_B, hid_H, alpha_now, beta_now, gamma_now, tau, out7);
+  return ick::launch_status("optloss_combine");
 }
 
 int ick_scale_by_scalar(float* x, const float* scalar, int64_t n, void* stream) {

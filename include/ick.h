@@ -180,6 +180,19 @@ int ick_kd_combine(const float* row_kl, const float* row_ce, int rows, const int
                    int Ef, const float* hid_part, int hid_steps, int hid_B, int hid_H, float w_ce, float alpha, float beta,
                    float gamma, float tau, float* out5, void* stream);                    /* :184-189 */
 int ick_scale_by_scalar(float* x, const float* scalar, int64_t n, void* stream);          /* x *= *scalar (device scalar) */
+/* OptimizedDistillationLoss (train_student_kd_optimized.py:34-128): soft-target cross entropy + focal
+ * loss per logits row with the gradient in the same pass (:51-56,:73-82); per-token cosine feature loss (:84-94);
+ * attention-weighted hidden MSE with caller-supplied softmaxed weights (:101-110); out7 in the reference's dict order. */
+int ick_token_softce_focal(const float* s, const float* t, const int64_t* targets, float* ds, float* row_kd, float* row_hard,
+                           int rows, int V, float tau, float g_kd, float g_hard, float focal_alpha, float focal_gamma,
+                           void* stream);
+int ick_feature_cosine(const float* s, const float* t, float* ds, float* dt, float* part, int64_t rows, int E, float gscale,
+                       void* stream);
+int ick_weighted_hidden_mse(const float* s, const float* t, const float* w, float* ds, float* part, int T, int B, int H,
+                            float gscale, void* stream);
+int ick_optloss_combine(const float* row_kd, const float* row_hard, int rows, const float* cos_part, int64_t cos_rows,
+                        const float* hid_part, int hid_B, int hid_H, float alpha_now, float beta_now, float gamma_now,
+                        float tau, float* out7, void* stream);
 
 /* ------------------------------------------------------------------ optimizer tail (train_student_kd.py:292-299)
  * flat fp32 buffers; clip_grad_norm_(max_norm) folded into the AdamW pass through the device-resident norm. */

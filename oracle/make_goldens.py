@@ -302,6 +302,47 @@ def golden_beam():
     npz("teacher_beam.npz", batch_seed=4321, **outs)
 
 
+def golden_optloss():
+    """N4: the reference's OptimizedDistillationLoss (/root/reference/src/train_student_kd_optimized.py:34-128), imported
+    with empty stand-ins for the two modules its file imports but the class does not use (torchvision.transforms,
+    data_loader).  Teacher hiddens are None as in the reference's train path (its hidden term draws torch.randn
+    attention weights, which no fixture can pin)."""
+    import types
+    import torchvision
+    tr = types.ModuleType("torchvision.transforms")
+    sys.modules["torchvision.transforms"] = tr
+    torchvision.transforms = tr
+    dl = types.ModuleType("data_loader")
+    dl.get_loader = None
+    sys.modules["data_loader"] = dl
+    import train_student_kd_optimized as ref_opt
+    g = torch.Generator().manual_seed(23)
+    T, B, Vl, E = 6, 5, 257, 64
+    out = {}
+    s_logits0 = torch.randn(T, B, Vl, generator=g) * 2
+    t_logits = torch.randn(T, B, Vl, generator=g) * 3
+    s_feat0 = torch.randn(B, 49, E, generator=g)
+    t_feat0 = torch.randn(B, 49, E, generator=g)
+    targets = torch.randint(0, Vl, (T, B), generator=g)
+    targets[4:, 1] = 0                                      # PAD tails (not ignored by this loss: plain CrossEntropyLoss)
+    out.update(s_logits=s_logits0, t_logits=t_logits, s_feat=s_feat0, t_feat=t_feat0, targets=targets)
+    for epoch in (0, 1, 3, 7):
+        s_logits = s_logits0.clone().requires_grad_(True)
+        s_feat = s_feat0.clone().requires_grad_(True)
+        t_feat = t_feat0.clone().requires_grad_(True)
+        L = ref_opt.OptimizedDistillationLoss(alpha=0.7, beta=0.2, gamma=0.1, temperature=4.0, vocab_size=Vl)
+        L.epoch = epoch
+        total, d = L({"logits": s_logits, "encoder_features": s_feat, "hidden_states": None},
+                     {"logits": t_logits, "encoder_features": t_feat, "hidden_states": None}, targets)
+        total.backward()
+        out[f"e{epoch}_values"] = np.array([d[k] for k in ("total_loss", "token_kd_loss", "feature_kd_loss", "hidden_kd_loss",
+                                                            "kd_loss", "hard_loss", "ce_loss")], np.float64)
+        out[f"e{epoch}_dlogits"] = s_logits.grad
+        out[f"e{epoch}_dsfeat"] = s_feat.grad if s_feat.grad is not None else torch.zeros_like(s_feat0)
+        out[f"e{epoch}_dtfeat"] = t_feat.grad if t_feat.grad is not None else torch.zeros_like(t_feat0)
+    npz("optloss.npz", **out)
+
+
 def golden_param_counts():
     """SURVEY.md §0 fact 10 — pins the architecture sizes."""
     torch.manual_seed(0)
@@ -320,9 +361,9 @@ def golden_param_counts():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "beam"]
+    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "beam", "optloss"]
     fns = {"counts": golden_param_counts, "losses": golden_losses, "projector": golden_projector,
            "refinement": golden_refinement, "decoders": golden_decoders, "cfg1": golden_cfg1,
-           "teacher": golden_teacher, "kd_step": golden_kd_step, "beam": golden_beam}
+           "teacher": golden_teacher, "kd_step": golden_kd_step, "beam": golden_beam, "optloss": golden_optloss}
     for w in which:
         fns[w]()

@@ -349,6 +349,37 @@ def distillation_loss(s_out: Dict, t_out: Dict, targets: torch.Tensor, *, alpha=
                    "feature_kd_loss": float(feat.detach()), "hidden_kd_loss": float(hid.detach())}
 
 
+def optimized_distillation_loss(s_out: Dict, t_out: Dict, targets: torch.Tensor, *, epoch: float = 0, alpha=0.7, beta=0.2,
+                                gamma=0.1, tau=4.0, focal_alpha=0.25, focal_gamma=2.0, warmup_epochs=3,
+                                attention_weights: Optional[torch.Tensor] = None):
+    """OptimizedDistillationLoss.forward, /root/reference/src/train_student_kd_optimized.py:58-128:
+    warm-up-scheduled weights (:63-66), soft-target cross entropy x tau^2 (:73-77), focal loss over ALL rows (plain
+    CrossEntropyLoss, PAD included, :51-56,:80), per-token cosine feature loss (:84-94), hidden term = MSE of
+    attention-weighted sums over time (:101-110; the reference draws the weights with torch.randn — here they are an
+    argument, softmaxed over time exactly as :106)."""
+    V = s_out["logits"].shape[-1]
+    wf = min(1.0, epoch / warmup_epochs)
+    ca, cb, cg = alpha * wf + (1 - wf) * 0.9, beta * wf, gamma * wf
+    s_logits, t_logits, tg = s_out["logits"].reshape(-1, V), t_out["logits"].reshape(-1, V), targets.reshape(-1)
+    kd = -(torch.softmax(t_logits / tau, -1) * torch.log_softmax(s_logits / tau, -1)).sum(-1).mean() * tau ** 2
+    ce = F.cross_entropy(s_logits, tg, reduction="none")
+    hard = (focal_alpha * (1 - torch.exp(-ce)) ** focal_gamma * ce).mean()
+    token = ca * kd + (1 - ca) * hard
+    feat = torch.tensor(0.0)
+    if "encoder_features" in s_out and "encoder_features" in t_out:
+        cos = (F.normalize(s_out["encoder_features"], p=2, dim=-1) * F.normalize(t_out["encoder_features"], p=2, dim=-1)).sum(-1)
+        feat = 1 - cos.mean()
+    hid = torch.tensor(0.0)
+    if s_out.get("hidden_states") is not None and t_out.get("hidden_states") is not None and attention_weights is not None:
+        sh, th = torch.stack(list(s_out["hidden_states"])), torch.stack(list(t_out["hidden_states"]))
+        w = torch.softmax(attention_weights, dim=0).unsqueeze(-1)
+        hid = F.mse_loss((sh * w).sum(0), (th * w).sum(0))
+    total = token + cb * feat + cg * hid
+    return total, {"total_loss": float(total.detach()), "token_kd_loss": float(token.detach()), "feature_kd_loss": float(feat.detach()),
+                   "hidden_kd_loss": float(hid.detach()), "kd_loss": float(kd.detach()), "hard_loss": float(hard.detach()),
+                   "ce_loss": float(hard.detach())}
+
+
 # ----------------------------------------------------------------------------- A14: one KD step
 def kd_forward_backward(student_sd: SD, teacher_sd: SD, proj_sd: SD, images: torch.Tensor, captions: torch.Tensor, *,
                         hidden: int, layers: int, refine: bool, t_heads: int, t_layers: int,

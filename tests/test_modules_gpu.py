@@ -315,3 +315,51 @@ def test_kd_trainer_full_step_vs_reference_golden(use_graph):
     torch.cuda.synchronize()
     assert not torch.equal(snap, sd["decoder.lstm.weight_hh_l0"].detach())
     assert tr.step_count == 2
+
+
+@pytest.mark.parametrize("epoch", [0, 1, 3, 7])
+def test_optimized_distillation_loss_vs_reference_golden(epoch):
+    """OptimizedDistillationLoss (reference train_student_kd_optimized.py:34-128) on the HIP path vs values
+    and gradients captured from the reference class (tests/golden/optloss.npz), for the warm-up epochs 0/1 and the
+    steady state; plus the hidden term with injected attention scores against the oracle restatement."""
+    from imagecaptioner_amd.train_student_kd_optimized import KEYS, OptimizedDistillationLoss
+    from oracle import restatement as R
+    g = load_golden("optloss.npz")
+
+    def rel_err(a, b):
+        a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(np.asarray(b) if not torch.is_tensor(b) else b.detach().cpu()).double()
+        return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+    s_logits, s_feat, t_feat = (t(g[k]).cuda().requires_grad_(True) for k in ("s_logits", "s_feat", "t_feat"))
+    L = OptimizedDistillationLoss(alpha=0.7, beta=0.2, gamma=0.1, temperature=4.0, vocab_size=257)
+    L.epoch = epoch
+    total, d = L({"logits": s_logits, "encoder_features": s_feat, "hidden_states": None},
+                 {"logits": t(g["t_logits"]).cuda(), "encoder_features": t_feat, "hidden_states": None}, t(g["targets"]).cuda())
+    total.backward()
+    want = g[f"e{epoch}_values"]
+    got = np.array([d[k] for k in KEYS])
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-6), (got, want)
+    assert rel_err(s_logits.grad, g[f"e{epoch}_dlogits"]) < 2e-5
+    if epoch > 0:
+        assert rel_err(s_feat.grad, g[f"e{epoch}_dsfeat"]) < 2e-5 and rel_err(t_feat.grad, g[f"e{epoch}_dtfeat"]) < 2e-5
+    else:                                             # beta_now = 0 during the first warm-up epoch
+        assert float(s_feat.grad.abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        OptimizedDistillationLoss(vocab_size=300)({"logits": s_logits}, {"logits": s_logits.detach()}, t(g["targets"]).cuda())
+    # hidden term: injected scores, oracle = restatement (the reference draws them with torch.randn -> unpinnable)
+    gen = torch.Generator().manual_seed(epoch)
+    sh = [torch.randn(5, 48, generator=gen) for _ in range(6)]
+    th = [torch.randn(5, 48, generator=gen) for _ in range(6)]
+    aw = torch.randn(6, 5, generator=gen)
+    sh_r = [x.clone().requires_grad_(True) for x in sh]
+    ref_total, ref_d = R.optimized_distillation_loss({"logits": t(g["s_logits"]), "hidden_states": sh_r},
+                                                      {"logits": t(g["t_logits"]), "hidden_states": th}, t(g["targets"]),
+                                                      epoch=epoch, attention_weights=aw)
+    ref_total.backward()
+    sh_d = [x.cuda().requires_grad_(True) for x in sh]
+    tot2, d2 = L({"logits": s_logits.detach(), "hidden_states": sh_d}, {"logits": t(g["t_logits"]).cuda(), "hidden_states": [x.cuda() for x in th]},
+                 t(g["targets"]).cuda(), attention_weights=aw.cuda())
+    assert abs(d2["hidden_kd_loss"] - ref_d["hidden_kd_loss"]) < 1e-5 and abs(d2["total_loss"] - ref_d["total_loss"]) < 2e-5 * abs(ref_d["total_loss"])
+    if epoch > 0:
+        tot2.backward()
+        assert rel_err(torch.stack([x.grad for x in sh_d]), torch.stack([x.grad for x in sh_r])) < 2e-5

@@ -199,3 +199,21 @@ def test_kd_step_train_mode():
     # BN running stats were updated in train mode, frozen stem included (fact 6)
     close(ssd["encoder.resnet.1.running_mean"], g["bn1_running_mean"], 1e-4, "bn1 running_mean")
     close(ssd["encoder.resnet.7.2.bn3.running_var"], g["l4_bn3_running_var"], 1e-4, "l4 bn3 running_var")
+
+
+@pytest.mark.parametrize("epoch", [0, 1, 3, 7])
+def test_optimized_distillation_loss(golden, epoch):
+    """N4: oracle restatement of the reference's OptimizedDistillationLoss vs goldens captured from the reference class."""
+    g = golden("optloss.npz")
+    s_logits, s_feat, t_feat = (t(g[k]).clone().requires_grad_(True) for k in ("s_logits", "s_feat", "t_feat"))
+    total, d = R.optimized_distillation_loss({"logits": s_logits, "encoder_features": s_feat, "hidden_states": None},
+                                             {"logits": t(g["t_logits"]), "encoder_features": t_feat, "hidden_states": None},
+                                             t(g["targets"]), epoch=epoch)
+    total.backward()
+    want = g[f"e{epoch}_values"]
+    got = np.array([d[k] for k in ("total_loss", "token_kd_loss", "feature_kd_loss", "hidden_kd_loss", "kd_loss", "hard_loss", "ce_loss")])
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6), (got, want)
+    assert torch.allclose(s_logits.grad, t(g[f"e{epoch}_dlogits"]), rtol=1e-4, atol=1e-8)
+    if epoch > 0:
+        assert torch.allclose(s_feat.grad, t(g[f"e{epoch}_dsfeat"]), rtol=1e-4, atol=1e-9)
+        assert torch.allclose(t_feat.grad, t(g[f"e{epoch}_dtfeat"]), rtol=1e-4, atol=1e-9)
