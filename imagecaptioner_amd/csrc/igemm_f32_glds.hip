@@ -19,6 +19,7 @@
 // Out-of-range elements (conv padding, M/N/K tails) are fetched from a 16-byte zero page instead of being masked
 // afterwards.  Two LDS buffers, one barrier per k-tile:  wait own DMA -> barrier -> issue DMA of tile t+1 -> MFMAs of t.
 #include "igemm_params.h"
+#include <cstdlib>
 #include <type_traits>
 #ifndef ICK_ABL
 #define ICK_ABL 0   // tools/ablate builds set 1..3 to price the epilogue and the DMA stream (never in libick.so)
@@ -34,6 +35,7 @@ constexpr int BK = 32;
 constexpr int NT = 256;
 
 __device__ __attribute__((aligned(16))) float g_zero16[4];   // the zero page
+const bool g_no_vec_epilogue = [] { const char* e = getenv("ICK_NO_VEC_EPILOGUE"); return e && e[0] == '1'; }();   // A/B runs
 
 // One LDS-DMA wave-instruction: lane l's 16 bytes at `src` land at LDS byte address lds_wave_base + 16*l.
 // Issued through inline asm on purpose: hipcc tracks the builtin form as an LDS write on the VM counter and then
@@ -329,6 +331,63 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
   const int mode = p.splitk > 1 ? 2 : (p.accumulate ? 1 : 0);
   const int act = p.act;
   const float alpha = p.alpha;
+  if (p.ep_vec && mode != 2) {
+    // LDS-staged epilogue: the block tile goes registers -> LDS (bias / activation applied, statistics taken on the
+    // way) and leaves as 16-byte stores along n, 2 x 512-byte rows (128-wide tiles) per wave-instruction instead of
+    // 2 x 128 bytes: the direct path below issues 4x the store instructions and prices 5-30 % of a short-K GEMM
+    // (profiles/r01g_ablation_glds.log, V1 -> V2).  The residual is read in the same coalesced pattern.
+    __syncthreads();                       // every wave is out of the k-loop: the LDS buffers become the C tile [BM][BN]
+    float* ct = lds;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = wn * WN + j * 32 + (lane & 31);
+      const int n = n0 + nl;
+      const bool nok = n < p.N;
+      const float bias = (biasp && nok) ? biasp[n] : 0.f;
+      float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WM + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = ml + (r & 3) + 8 * (r >> 2);
+          const float v = acc[i][j][r] * alpha;
+          if (nok && m0 + row < p.M) { ssum += v; ssq += v * v; }
+          ct[row * BN + nl] = act_fn(v + bias, act);
+        }
+      }
+      if (p.stat_sum) {
+        ssum += __shfl_xor(ssum, 32);
+        ssq += __shfl_xor(ssq, 32);
+        if (lane < 32 && nok) {
+          const long so = (long)(tile_m % p.stat_copies) * p.stat_stride + n;
+          atomicAdd(p.stat_sum + so, (double)ssum); atomicAdd(p.stat_sq + so, (double)ssq);
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    for (int c = tid; c < BM * C4; c += NT) {
+      const int row = c / C4, col = (c - row * C4) * 4;
+      const int m = m0 + row, n = n0 + col;
+      if (m < p.M && n < p.N) {            // N % 4 == 0 on this path: the whole chunk is in range
+        long mr = m;
+        if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
+          const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
+          mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
+        }
+        float4 v = *reinterpret_cast<const float4*>(ct + row * BN + col);
+        if (Rg) {
+          const float4 q = *reinterpret_cast<const float4*>(Rg + mr * p.ldr + n);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(Cg + mr * p.ldc + n);
+        if (mode == 1) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
+      }
+    }
+    return;
+  }
   auto epilogue = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -382,6 +441,9 @@ template <int OP, int BM, int BN, int NBUF>
 int launch(const P& p0, int nz, hipStream_t st) {
   P p = p0;
   p.tiles_n = (p.N + BN - 1) / BN;
+  // 16-byte stores need every row start of C (and of the residual) 16-byte aligned
+  p.ep_vec = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.sCo | p.sCi) % 4 == 0 && ick::aligned16(p.C) &&
+             (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual))) && !g_no_vec_epilogue;
   dim3 grid(p.tiles_n * ((p.M + BM - 1) / BM), 1, nz);
   ICK_LAUNCH((igemm_f32_glds_kernel<OP, BM, BN, NBUF>), grid, dim3(NT), 0, st, p);
   return ick::launch_status("igemm_f32_glds");

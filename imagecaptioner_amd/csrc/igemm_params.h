@@ -16,6 +16,7 @@ struct P {  // kernel parameters (by value)
   float alpha;
   int Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
   int stat_copies; long stat_stride;
+  int ep_vec;   // LDS-staged 16-byte epilogue allowed (set by the launcher from the alignment of C / residual)
 };
 
 // which fetch pattern each op uses for its A and B operands
