@@ -75,7 +75,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
   constexpr int A_SZ = img_elems<AK, BM>(), B_SZ = img_elems<BKc, BN>();
   constexpr int BUF = IMGS * (A_SZ + B_SZ);
 
-  __shared__ __attribute__((aligned(16))) u16 lds[2 * BUF];   // [buffer][A hi, A lo, B hi, B lo]
+  constexpr int LDS_ELEMS = 2 * BUF > 2 * BM * BN ? 2 * BUF : 2 * BM * BN;   // also holds the fp32 C tile of the staged epilogue
+  __shared__ __attribute__((aligned(16))) u16 lds[LDS_ELEMS];   // [buffer][A hi, A lo, B hi, B lo]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -367,6 +368,62 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
   const int mode = p.splitk > 1 ? 2 : (p.accumulate ? 1 : 0);
   const int act = p.act;
   const float alpha = p.alpha;
+  if (p.ep_vec && mode != 2) {
+    // LDS-staged epilogue (see igemm_f32_glds.hip): registers -> LDS tile [BM][BN] -> 16-byte row stores; at bf16 MFMA
+    // rates the epilogue is a large share of a short-K convolution
+    __syncthreads();
+    float* ct = reinterpret_cast<float*>(lds);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nl = wn * WN + j * 32 + (lane & 31);
+      const int n = n0 + nl;
+      const bool nok = n < p.N;
+      const float bias = (biasp && nok) ? biasp[n] : 0.f;
+      float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int ml = wm * WM + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = ml + (r & 3) + 8 * (r >> 2);
+          const float v = acc[i][j][r] * alpha;
+          if (nok && m0 + row < p.M) { ssum += v; ssq += v * v; }
+          ct[row * BN + nl] = act_fn(v + bias, act);
+        }
+      }
+      if (p.stat_sum) {
+        ssum += __shfl_xor(ssum, 32);
+        ssq += __shfl_xor(ssq, 32);
+        if (lane < 32 && nok) {
+          const long so = (long)(tile_m % p.stat_copies) * p.stat_stride + n;
+          atomicAdd(p.stat_sum + so, (double)ssum); atomicAdd(p.stat_sq + so, (double)ssq);
+        }
+      }
+    }
+    __syncthreads();
+    constexpr int C4 = BN / 4;
+    for (int c = tid; c < BM * C4; c += NT) {
+      const int row = c / C4, col = (c - row * C4) * 4;
+      const int m = m0 + row, n = n0 + col;
+      if (m < p.M && n < p.N) {
+        long mr = m;
+        if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
+          const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
+          mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
+        }
+        float4 v = *reinterpret_cast<const float4*>(ct + row * BN + col);
+        if (Rg) {
+          const float4 q = *reinterpret_cast<const float4*>(Rg + mr * p.ldr + n);
+          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        float4* dst = reinterpret_cast<float4*>(Cg + mr * p.ldc + n);
+        if (mode == 1) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
+      }
+    }
+    return;
+  }
   auto epilogue = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
@@ -416,6 +473,8 @@ template <int OP, int BM, int BN, int TERMS>
 int launch(const P& p0, int nz, hipStream_t st) {
   P p = p0;
   p.tiles_n = (p.N + BN - 1) / BN;
+  p.ep_vec = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.sCo | p.sCi) % 4 == 0 && ick::aligned16(p.C) &&
+             (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual)));
   dim3 grid(p.tiles_n * ((p.M + BM - 1) / BM), 1, nz);
   ICK_LAUNCH((igemm_bf16_kernel<OP, BM, BN, TERMS>), grid, dim3(NT), 0, st, p);
   return ick::launch_status("igemm_bf16");
