@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
       const int n = n0 + wn * WN + j * 32 + (lane & 31);
       const bool nok = FULL || n < p.N;
       const float bias = (biasp && nok) ? biasp[n] : 0.f;
-      float ssum = 0.f, ssq = 0.f;
+      float ssum = 0.f, ssq = 0.f;   // ssq by explicit fmaf: the epilogue variants must agree bit for bit
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int mb = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
           const int m = mb + (r & 3) + 8 * (r >> 2);
           if (FULL || (m < p.M && nok)) {
             float v = acc[i][j][r] * alpha;
-            ssum += v; ssq += v * v;
+            ssum += v; ssq = fmaf(v, v, ssq);
             v = act_fn(v + bias, act);
             long mr = m;
             if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // class row -> pixel row of the full-resolution dX
@@ -434,11 +434,16 @@ static bool want_glds(const IckGemm* d) {
 
 extern "C" int ick_gemm_f32(const IckGemm* d0, void* stream) {
   ICK_REQUIRE(d0 != nullptr, "ick_gemm_f32: null descriptor");
-  const bool glds = want_glds(d0);
+  const bool fused_bn = d0->col_scale || (d0->act & ICK_ACT_POST_RESIDUAL);   // only the LDS-DMA kernel implements these
+  const bool glds = want_glds(d0) || (fused_bn && glds_eligible(d0));
+  ICK_REQUIRE(glds || (!d0->col_scale && !(d0->act & ICK_ACT_POST_RESIDUAL)),
+              "ick_gemm_f32: col_scale / ICK_ACT_POST_RESIDUAL are implemented by the LDS-DMA kernel only (K %% 4, Cin %% 32)");
   IckGemm dd = *d0; dd.tile &= 255;
+  const int no_ep_vec = (d0->tile >> 9) & 1;
   const IckGemm* d = &dd;
   P p; int nz = 1;
   if (int rc = prepare(d, glds ? 32 : BK, p, nz, "ick_gemm_f32")) return rc;
+  p.no_ep_vec = no_ep_vec;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (d->op) {
     case ICK_OP_NT:

