@@ -181,9 +181,37 @@ __global__ void argmax_rows_kernel(const float* __restrict__ x, long* __restrict
   for (long r = blockIdx.x * (long)wpb + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * wpb) {
     const float* xr = x + r * ld;
     float best = -INFINITY; int bi = V;
-    for (int i = lane; i < V; i += 64) {
-      const float v = xr[i];
-      if (v > best) { best = v; bi = i; }   // strict > keeps the first maximum within a lane
+    // 16-byte loads, 4 of them in flight per lane (a 4-byte load per dependent compare left the wave latency-bound:
+    // 78 round trips per 5000-word row); indices grow with every step, strict > keeps the first maximum
+    if ((ld & 3) == 0 && (V & 3) == 0) {
+      const int V4 = V >> 2;
+      int i = lane;
+      for (; i + 192 < V4; i += 256) {
+        float4 q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = reinterpret_cast<const float4*>(xr)[i + 64 * u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int b = (i + 64 * u) * 4;
+          if (q[u].x > best) { best = q[u].x; bi = b; }
+          if (q[u].y > best) { best = q[u].y; bi = b + 1; }
+          if (q[u].z > best) { best = q[u].z; bi = b + 2; }
+          if (q[u].w > best) { best = q[u].w; bi = b + 3; }
+        }
+      }
+      for (; i < V4; i += 64) {
+        const float4 q = reinterpret_cast<const float4*>(xr)[i];
+        const int b = i * 4;
+        if (q.x > best) { best = q.x; bi = b; }
+        if (q.y > best) { best = q.y; bi = b + 1; }
+        if (q.z > best) { best = q.z; bi = b + 2; }
+        if (q.w > best) { best = q.w; bi = b + 3; }
+      }
+    } else {
+      for (int i = lane; i < V; i += 64) {
+        const float v = xr[i];
+        if (v > best) { best = v; bi = i; }   // strict > keeps the first maximum within a lane
+      }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -247,12 +247,25 @@ class _Arena:
         return v
 
 
+def _eval_coeffs(bn: BatchNorm2d) -> torch.Tensor:
+    """(scale, shift) of an eval-mode BatchNorm, cached on the module until one of its four tensors changes (in-place
+    version counters / storage), so that repeated inference does not relaunch 53 tiny kernels per forward."""
+    ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple((t.data_ptr(), t._version) for t in ts)
+    cached = getattr(bn, "_ick_eval_co", None)
+    if cached is None or cached[0] != key:
+        cached = (key, ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps))
+        bn._ick_eval_co = cached
+    return cached[1]
+
+
 def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool, w_packed=None, arena=None, counters=None):
     """raw = conv(x); y = [relu](bn(raw) [+ residual]).  Train mode: batch statistics from the conv epilogue (fp64
     sums), normalisation + running-stat update in one pass over raw (also for frozen layers).
     Returns (y, raw, mean, invstd)."""
     w = w_packed if w_packed is not None else conv.packed()
     if train:
+        bn._ick_eval_co = None       # running statistics (and soon the affine parameters) change under raw kernels
         C = w.shape[0]
         Ho, Wo = ops.conv_out_hw(x.shape[1], x.shape[2], w.shape[1], w.shape[2], conv.stride, conv.padding)
         R = ops.stat_copies(x.shape[0] * Ho * Wo)
@@ -268,7 +281,7 @@ def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool,
         return y, raw, mean, inv
     # eval mode: BatchNorm is a per-channel affine map -> folded into the conv epilogue (no second pass over the output);
     # same arithmetic as the two-pass form: fmaf(conv, scale, shift) + residual, then ReLU
-    co = ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+    co = _eval_coeffs(bn)
     y = ops.conv_fwd(x, w, conv.stride, conv.padding, scale=co[0], shift=co[1], residual=residual, relu=relu)
     return y, None, None, None
 
