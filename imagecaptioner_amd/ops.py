@@ -48,12 +48,13 @@ _FORCE_TILE = [0]       # tools/profile_step_gemms.py sweeps tile shapes through
 _TILE_OR = [0]          # diagnostics: bits OR-ed into every descriptor's tile field (512 = direct epilogue)
 
 
-def _load_tuned():
+def _load_tuned(name: str = "tuned_tiles.json"):
     """Measured best tile per (op, M, N, K, batch, splitk) for the KD step's shapes (tools/profile_step_gemms.py on an
     MI355X); shapes not in the table use the library's wave-quantisation model."""
     import json
     import os
-    path = os.environ.get("ICK_TUNED_TABLE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_tiles.json")
+    path = (os.environ.get("ICK_TUNED_TABLE") if name == "tuned_tiles.json" else None) or \
+        os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
     if os.environ.get("ICK_NO_TUNED") == "1":      # A/B runs: the library's own tile model only
         return {}
     try:
@@ -63,6 +64,7 @@ def _load_tuned():
 
 
 _TUNED = _load_tuned()
+_TUNED_BF16 = _load_tuned("tuned_tiles_bf16.json")     # same keys, for the bf16 / bf16x3 kernel family
 
 # Arithmetic of every dense contraction (Linear / attention products / convolutions): "f32" = exact fp32 MFMA (the
 # parity regime), "bf16" = bf16 MFMA with fp32 accumulation (the reference's autocast regime, train_student_kd.py:263),
@@ -119,7 +121,7 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
         d.Nb, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.R, d.S, d.stride, d.pad = conv
     terms = _PRECISIONS[_PREC[0]]
     if terms:
-        d.tile = tile or _FORCE_TILE[0]
+        d.tile = tile or _FORCE_TILE[0] or _TUNED_BF16.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
         check(_lib.lib().ick_gemm_bf16(ctypes.byref(d), terms, _st()), "ick_gemm_bf16")
         return
     d.tile = (tile or _FORCE_TILE[0] or _TUNED.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)) | _TILE_OR[0]

@@ -15,12 +15,15 @@ from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models  # no
 from imagecaptioner_amd.utils.seeded_init import synthetic_batch  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"     # "bf16": sweep the bf16 family (student side of the AMP step)
 OPN = ["NT", "NN", "TN", "CONV_FWD", "CONV_FWD_C4", "CONV_DGRAD", "CONV_WGRAD", "CONV_DGRAD_S2"]
 records = []
 orig = ops.gemm_raw
 
 
 def rec(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw):
+    if (ops.gemm_precision() == "f32") != (PREC == "f32"):        # AMP: only the student's bf16 launches are swept
+        return orig(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw)
     records.append((op, M, N, K, lda, ldb, ldc, kw.get("batch", (1, 1)), kw.get("strides", (0,) * 6), kw.get("splitk", 1),
                     kw.get("conv"), kw.get("act", 0), kw.get("bias") is not None, kw.get("residual") is not None,
                     kw.get("stat_sum") is not None, kw.get("accumulate", False), kw.get("ldr", 0)))
@@ -28,7 +31,9 @@ def rec(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw):
 
 
 student, teacher, projectors = build_kd_models(device="cuda")
-tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=B, use_graph=False)
+tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=B, use_graph=False, precision=PREC, overlap_teacher=False)
+if PREC != "f32":
+    ops._TUNED_BF16.clear()
 images, caps = synthetic_batch(B, 5000, 16)
 tr.train_step(images.cuda(), caps.cuda())
 ops.gemm_raw = rec
@@ -43,6 +48,9 @@ stat = torch.zeros(2, 4096, dtype=torch.float64, device="cuda")
 rows = []
 TN_ = ["model", "128x128", "64x64", "128x64", "64x128", "3b64x64", "3b128x64", "3b64x128", "r128x128", "r64x64", "r128x64", "r64x128"]
 TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260]   # +16: three LDS buffers; +256: the register-staged kernel
+if PREC != "f32":
+    TN_, TILES = TN_[:5], TILES[:5]
+    ops.set_gemm_precision(PREC)
 
 
 def timeit(f, iters=10):
@@ -89,7 +97,8 @@ table = {}
 for tt, n, t, tf, opn, M, N, K, nb, sk, conv, ts, best in rows:
     if ts[best] < 0.97 * ts[0]:
         table[f"{OPN.index(opn)}:{M}:{N}:{K}:{nb}:{sk}"] = TILES[best]
-out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", f"tuned_tiles_B{B}.json")
+out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
+                        f"tuned_tiles_B{B}.json" if PREC == "f32" else f"tuned_tiles_{PREC}_B{B}.json")
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(table, open(out_path, "w"), indent=0, sort_keys=True)
 print(f"wrote {len(table)} tuned entries to {out_path}")
