@@ -30,15 +30,30 @@ def rec(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw):
     return orig(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw)
 
 
-student, teacher, projectors = build_kd_models(device="cuda")
-tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=B, use_graph=False, precision=PREC, overlap_teacher=False)
-if PREC != "f32":
-    ops._TUNED_BF16.clear()
-images, caps = synthetic_batch(B, 5000, 16)
-tr.train_step(images.cuda(), caps.cuda())
-ops.gemm_raw = rec
-tr.train_step()
-ops.gemm_raw = orig
+WORKLOAD = sys.argv[3] if len(sys.argv) > 3 else "kd"    # "cfg2": student eval forward + 20-token greedy decode at batch B
+if WORKLOAD == "cfg2":
+    from imagecaptioner_amd.student_model import CaptioningStudent
+    from imagecaptioner_amd.utils.seeded_init import apply_seeded_init
+    m = apply_seeded_init(CaptioningStudent(5000, 256, 512, 2), 0).cuda().eval()
+    images, _ = synthetic_batch(B, 5000, 16, seed=4321)
+    images = images.cuda()
+    if PREC != "f32":
+        ops._TUNED_BF16.clear()
+    with ops.precision(PREC):
+        m.generate(images, 20)
+        ops.gemm_raw = rec
+        m.generate(images, 20)
+        ops.gemm_raw = orig
+else:
+    student, teacher, projectors = build_kd_models(device="cuda")
+    tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=B, use_graph=False, precision=PREC, overlap_teacher=False)
+    if PREC != "f32":
+        ops._TUNED_BF16.clear()
+    images, caps = synthetic_batch(B, 5000, 16)
+    tr.train_step(images.cuda(), caps.cuda())
+    ops.gemm_raw = rec
+    tr.train_step()
+    ops.gemm_raw = orig
 torch.cuda.synchronize()
 print(f"{len(records)} igemm launches per step at B={B}")
 cnt = collections.Counter(records)
@@ -98,7 +113,8 @@ for tt, n, t, tf, opn, M, N, K, nb, sk, conv, ts, best in rows:
     if ts[best] < 0.97 * ts[0]:
         table[f"{OPN.index(opn)}:{M}:{N}:{K}:{nb}:{sk}"] = TILES[best]
 out_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out",
-                        f"tuned_tiles_B{B}.json" if PREC == "f32" else f"tuned_tiles_{PREC}_B{B}.json")
+                        (f"tuned_tiles_B{B}.json" if PREC == "f32" else f"tuned_tiles_{PREC}_B{B}.json") if WORKLOAD == "kd"
+                        else f"tuned_tiles_{PREC}_{WORKLOAD}_B{B}.json")
 os.makedirs(os.path.dirname(out_path), exist_ok=True)
 json.dump(table, open(out_path, "w"), indent=0, sort_keys=True)
 print(f"wrote {len(table)} tuned entries to {out_path}")
