@@ -22,6 +22,7 @@
 // Global->LDS is register-staged (the fp32->bf16 rounding has to happen in flight): tile t+1's loads are issued
 // before tile t's MFMAs and written to the other LDS buffer after them; one barrier per k-tile.
 #include "igemm_params.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -531,6 +532,11 @@ int run(const IckGemm* d, const P& p, int nz, hipStream_t st) {
 
 }  // namespace
 
+namespace ickg {
+bool glds_eligible(const IckGemm* d);                                                     // igemm_f32_glds.hip
+int run_glds_bf16(const IckGemm* d, int terms, const P& p, int nz, hipStream_t st);       // igemm_bf16_glds.hip
+}
+
 extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
   ICK_REQUIRE(terms == 1 || terms == 3, "ick_gemm_bf16: terms must be 1 (bf16) or 3 (split bf16), got %d", terms);
   P p; int nz = 1;
@@ -572,5 +578,13 @@ extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
     default:
       return ick::fail(-1, "ick_gemm_bf16: unknown op %d", d->op);
   }
-  return terms == 3 ? run<3>(d, p, nz, st) : run<1>(d, p, nz, st);
+  // the LDS-DMA variant (igemm_bf16_glds.hip) is the default where it exists; IckGemm.tile bit 8 or ICK_NO_GLDS_BF16=1
+  // selects this file's register-staged kernel (conv wgrad always: both operands x-contiguous + per-lane gather)
+  static const bool no_glds = [] { const char* e = getenv("ICK_NO_GLDS_BF16"); return e && e[0] == '1'; }();
+  if (!no_glds && !(d->tile & 256) && d->op != ICK_OP_CONV_WGRAD && glds_eligible(d)) {
+    IckGemm dd = *d; dd.tile &= 255;
+    return run_glds_bf16(&dd, terms, p, nz, st);
+  }
+  IckGemm dd = *d; dd.tile &= 15;      // the register-staged family has the four plain tile shapes only
+  return terms == 3 ? run<3>(&dd, p, nz, st) : run<1>(&dd, p, nz, st);
 }

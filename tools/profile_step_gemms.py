@@ -64,7 +64,6 @@ rows = []
 TN_ = ["model", "128x128", "64x64", "128x64", "64x128", "3b64x64", "3b128x64", "3b64x128", "r128x128", "r64x64", "r128x64", "r64x128"]
 TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260]   # +16: three LDS buffers; +256: the register-staged kernel
 if PREC != "f32":
-    TN_, TILES = TN_[:5], TILES[:5]
     ops.set_gemm_precision(PREC)
 
 
