@@ -205,6 +205,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dominant-kernel-only", action="store_true",
+                    help="only time the dominant kernel in isolation (for the matching rocprofv3 --kernel-trace --stats run)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (bf16 step, cfg2 decode) at N=1")
     ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream instead of a parallel graph branch")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3"],
@@ -225,6 +227,9 @@ def main():
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     log = (lambda m: print(f"[bench rank {rank}] {m}", file=sys.stderr, flush=True))
+    if args.dominant_kernel_only:
+        print(json.dumps({"dominant_kernel": dominant_kernel(dev, iters=50)}), flush=True)
+        return
     ips, dt, dev_ms, loss = run_kd(args, args.precision, dev, rank, world, log)
     if rank == 0:
         ips = world * args.batch * args.steps / dt

@@ -29,7 +29,7 @@ def close_l2(a, b, tol, name=""):
     """relative L2 error over the (sliced) tensor — the metric for end-to-end gradients through the train-mode
     ResNet trunk.  Those gradients are ill-conditioned at B=2 (98 samples per BatchNorm channel + ReLU masks): the
     REFERENCE's own fp32 CPU arithmetic sits 1-2e-2 (rel. L2) away from an fp64 evaluation of the same graph
-    (tools/diag_grads.py prints both columns; profiles/diag_grads_r01.log), so tighter bounds would test noise."""
+    (tests/diag_grads.py prints both columns; profiles/diag_grads_r01.log), so tighter bounds would test noise."""
     a = torch.as_tensor(a).detach().double().cpu().flatten()
     b = torch.as_tensor(np.asarray(b)).double().flatten()
     assert a.shape == b.shape, name
