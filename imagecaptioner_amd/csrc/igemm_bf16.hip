@@ -534,7 +534,7 @@ int run(const IckGemm* d, const P& p, int nz, hipStream_t st) {
 
 namespace ickg {
 bool glds_eligible(const IckGemm* d);                                                     // igemm_f32_glds.hip
-int run_glds_bf16(const IckGemm* d, int terms, const P& p, int nz, hipStream_t st);       // igemm_bf16_glds.hip
+int run_glds_bf16(const IckGemm* d, int terms, const P& p, int nz, hipStream_t st);       // igemm_bf16_glds_impl.h
 }
 
 extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
@@ -578,7 +578,7 @@ extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
     default:
       return ick::fail(-1, "ick_gemm_bf16: unknown op %d", d->op);
   }
-  // the LDS-DMA variant (igemm_bf16_glds.hip) is the default where it exists; IckGemm.tile bit 8 or ICK_NO_GLDS_BF16=1
+  // the LDS-DMA variant (igemm_bf16_glds_impl.h) is the default where it exists; IckGemm.tile bit 8 or ICK_NO_GLDS_BF16=1
   // selects this file's register-staged kernel (conv wgrad always: both operands x-contiguous + per-lane gather)
   static const bool no_glds = [] { const char* e = getenv("ICK_NO_GLDS_BF16"); return e && e[0] == '1'; }();
   if (!no_glds && !(d->tile & 256) && d->op != ICK_OP_CONV_WGRAD && glds_eligible(d)) {

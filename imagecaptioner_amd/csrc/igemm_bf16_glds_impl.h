@@ -1,4 +1,4 @@
-// igemm_bf16_glds.hip — the bf16 / split-bf16 MFMA family with DIRECT global->LDS staging (LDS-DMA).
+// igemm_bf16_glds_impl.h — the bf16 / split-bf16 MFMA family with DIRECT global->LDS staging (LDS-DMA).
 //
 // Same DMA pipeline, LDS images (fp32!), zero page, buffering and epilogues as igemm_f32_glds.hip; only the compute
 // differs: fragments are read from the fp32 images (two ds_read_b128 = 8 consecutive k per lane for k-contiguous
@@ -8,6 +8,7 @@
 // latency-bound (385 TF at 4096^3); the DMA ring keeps 1-2 whole tiles in flight per workgroup with no staging
 // registers and no conversion pass through the LDS write port.  TERMS == 3 splits each fp32 value into hi + lo bf16
 // parts in registers (hi*hi + hi*lo + lo*hi).
+#pragma once
 #include "igemm_params.h"
 #include <cstdlib>
 #include <type_traits>
@@ -487,8 +488,10 @@ int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
 
 namespace ickg {
 
-template <int TERMS>
-static int run_terms(const IckGemm* d, const P& p, int nz, hipStream_t st) {
+// one translation unit per TERMS value (igemm_bf16_glds_t1.hip / _t3.hip): the 49 kernel instantiations of each compile
+// in parallel instead of 98 in one 2.5-minute hipcc run
+int ICK_BF16_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
+  constexpr int TERMS = ICK_BF16_GLDS_TERMS;
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
     case ICK_OP_NN: return dispatch_tile<ICK_OP_NN, TERMS>(p, nz, st, d->tile);
@@ -499,11 +502,6 @@ static int run_terms(const IckGemm* d, const P& p, int nz, hipStream_t st) {
     case ICK_OP_CONV_DGRAD_S2: return dispatch_tile<ICK_OP_CONV_DGRAD_S2, TERMS>(p, 4, st, d->tile);
     default: return ick::fail(-1, "ick_gemm_bf16: op %d has no LDS-DMA variant", d->op);
   }
-}
-
-// argument checks are done by the caller (ick_gemm_bf16); p/nz come from prepare(d, 32, ...); eligibility = glds_eligible
-int run_glds_bf16(const IckGemm* d, int terms, const P& p, int nz, hipStream_t st) {
-  return terms == 3 ? run_terms<3>(d, p, nz, st) : run_terms<1>(d, p, nz, st);
 }
 
 }  // namespace ickg
