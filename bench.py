@@ -80,7 +80,7 @@ def cpu_baseline(batch: int = 16):
     run = lambda: R.kd_forward_backward(ssd, tsd, psd, images, caps, hidden=512, layers=2, refine=True, t_heads=8, t_layers=4)
     run()                                   # warm-up (thread pools, allocator)
     steps, t0 = 0, time.perf_counter()
-    while steps < 2 or (time.perf_counter() - t0 < 10.0 and steps < 6):
+    while steps < 2 or (time.perf_counter() - t0 < 12.0 and steps < 40):    # ~12 s of CPU work
         for v in list(ssd.values()) + list(psd.values()):
             v.grad = None
         run()
