@@ -248,3 +248,30 @@ def test_evaluator_metrics_known_answers():
     assert ev.meteor_score_simple("", "a dog") == 0.0 and ev.meteor_score_simple("cat", "") == 0.0
     assert ev.reference_caption([1, 4, 5, 6, 2, 0, 0]) == "a dog runs"
     assert ev._words([4, 5, 2, 6]) == ["a", "dog"]
+
+
+def test_optimized_loss_warmup_schedule_host_logic():
+    """OptimizedDistillationLoss.current_weights = the reference's adaptive weights (train_student_kd_optimized.py:63-66)."""
+    from imagecaptioner_amd.train_student_kd_optimized import KEYS, OptimizedDistillationLoss
+    L = OptimizedDistillationLoss(alpha=0.7, beta=0.2, gamma=0.1)
+    assert KEYS == ("total_loss", "token_kd_loss", "feature_kd_loss", "hidden_kd_loss", "kd_loss", "hard_loss", "ce_loss")
+    L.epoch = 0
+    assert L.current_weights() == pytest.approx((0.9, 0.0, 0.0))
+    L.epoch = 1.5
+    assert L.current_weights() == pytest.approx((0.7 * 0.5 + 0.45, 0.1, 0.05))
+    L.epoch = 30
+    assert L.current_weights() == pytest.approx((0.7, 0.2, 0.1))
+    with pytest.raises(RuntimeError):           # no GPU here: the loss has no CPU fallback
+        import torch
+        z = torch.zeros(2, 2, 5000)
+        L({"logits": z}, {"logits": z}, torch.zeros(2, 2, dtype=torch.long))
+
+
+def test_gpu_transform_refuses_cpu():
+    import numpy as np
+    import torch
+    from imagecaptioner_amd.data_pipeline import GpuImageTransform
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        GpuImageTransform(train=False, device="cpu")([np.zeros((10, 10, 3), np.uint8)])
