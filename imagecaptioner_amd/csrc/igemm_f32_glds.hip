@@ -44,6 +44,9 @@ const bool g_no_vec_epilogue = [] { const char* e = getenv("ICK_NO_VEC_EPILOGUE"
 // vmcnt wait that matters is the explicit one at the top of each iteration.
 __device__ __forceinline__ void glds16(const float* src, unsigned lds_wave_base) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);
+#if ICK_ABL == 5   // timing experiment: every DMA is issued but fetches the zero page (issue cost without operand traffic)
+  src = g_zero16;
+#endif
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory");
 }
 
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mb + (r & 3) + 8 * (r >> 2);
-          if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL == 4 || alpha == 12345.f)) {
+          if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL >= 4 || alpha == 12345.f)) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq = fmaf(v, v, ssq);
             v = act_fn(v + bias, act);
@@ -423,7 +426,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
           }
         }
       }
-      if (p.stat_sum && (ICK_ABL < 1 || ICK_ABL == 4 || alpha == 12345.f)) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
+      if (p.stat_sum && (ICK_ABL < 1 || ICK_ABL >= 4 || alpha == 12345.f)) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
         ssum += __shfl_xor(ssum, 32);
         ssq += __shfl_xor(ssq, 32);
         if (lane < 32 && nok) {

@@ -14,11 +14,11 @@ cases = [("NT 4096^3", 0, 4096, 4096, 4096, None, 1), ("NT 12608x1536x384", 0, 1
          ("conv1x1 28x28 128->512", 3, B * 28 * 28, 512, 128, (B, 28, 28, 128, 28, 28, 512, 1, 1, 1, 0), 3),
          ("dgrad3x3 14x14 256->256", 5, B * 14 * 14, 256, 2304, (B, 14, 14, 256, 14, 14, 256, 3, 3, 1, 1), 4)]
 libs = []
-for n in (0, 1, 2, 3, 4):
+for n in (0, 1, 2, 3, 4, 5):
     L = ctypes.CDLL(os.path.join(here, f"libglds{n}.so")); L.ick_gemm_f32.argtypes = [ctypes.c_void_p, ctypes.c_void_p]; libs.append(L)
 for name, op, M, N, K, conv, tile in cases:
     line = f"{name:26s}"
-    for n, L in zip((0, 1, 2, 3, 4), libs):
+    for n, L in zip((0, 1, 2, 3, 4, 5), libs):
         d = IckGemm(); d.A, d.B, d.C = x.data_ptr(), w.data_ptr(), y.data_ptr()
         d.op = op; d.M, d.N, d.K = M, N, K; d.lda, d.ldb, d.ldc = K, K, N; d.batch_outer = d.batch_inner = 1; d.splitk = 1; d.alpha = 1.0; d.tile = tile
         if conv:
