@@ -32,12 +32,12 @@ PEAK_BF16_MFMA_TF = 2516.0      # same guide: ~2.5 PF dense bf16 (v_mfma_f32_32x
 GFLOP_TEACHER, GFLOP_STUDENT = 9.80, 18.61
 
 
-def mfma_peak(precision: str):
+def mfma_peak(precision: str, gflop_student: float = GFLOP_STUDENT):
     """Roofline denominator for the step: the teacher always runs on the fp32 MFMA; the student's contractions run on
     the fp32 MFMA ("f32"), on the bf16 MFMA ("bf16") or as 3 bf16 MFMAs per product ("bf16x3").  The blended peak
     is total FLOPs / (time of each part at its own MFMA peak)."""
     ps = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 3}[precision]
-    return GFLOP_PER_IMAGE / (GFLOP_TEACHER / PEAK_F32_MFMA_TF + GFLOP_STUDENT / ps)
+    return (GFLOP_TEACHER + gflop_student) / (GFLOP_TEACHER / PEAK_F32_MFMA_TF + gflop_student / ps)
 BATCH = 64
 VOCAB, T1 = 5000, 16
 
@@ -97,7 +97,8 @@ def run_kd(args, precision, dev, rank, world, log):
     from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
     from imagecaptioner_amd.utils.seeded_init import synthetic_batch
 
-    student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev)    # identical init on every rank
+    dims = dict(embed_size=384, hidden_size=768, num_layers=3) if args.student == "cfg5" else {}
+    student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev, **dims)   # identical init on every rank
     trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
                         use_graph=not args.no_graph, precision=precision, overlap_teacher=not args.no_overlap)
     images, caps = synthetic_batch(args.batch, VOCAB, T1, seed=1234, rank=rank)     # rank-specific shard of the global batch
@@ -205,6 +206,9 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH, help="per-GPU batch (BASELINE: 64)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--student", default="cfg3", choices=["cfg3", "cfg5"],
+                    help="cfg3 (default, the metric's config): student 256/512/2-layer; cfg5: the large student 384/768/3-layer "
+                         "(BASELINE configs[4]; use --batch 32 for its per-GPU batch)")
     ap.add_argument("--dominant-kernel-only", action="store_true",
                     help="only time the dominant kernel in isolation (for the matching rocprofv3 --kernel-trace --stats run)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (bf16 step, cfg2 decode) at N=1")
@@ -234,8 +238,9 @@ def main():
     if rank == 0:
         ips = world * args.batch * args.steps / dt
         step_ms_dev = dev_ms / args.steps
-        achieved = GFLOP_PER_IMAGE * args.batch / step_ms_dev            # GFLOP / ms = TFLOP/s, this rank's GPU
-        peak = mfma_peak(args.precision)
+        gflop_img = GFLOP_PER_IMAGE if args.student == "cfg3" else 30.7   # cfg5 = 30.7 algorithmic GFLOP/image
+        achieved = gflop_img * args.batch / step_ms_dev                   # GFLOP / ms = TFLOP/s, this rank's GPU
+        peak = mfma_peak(args.precision, gflop_img - GFLOP_TEACHER)
         dtype = {"f32": "f32", "bf16": "bf16 student (fp32 accumulate, fp32 master weights) + f32 teacher",
                  "bf16x3": "split-bf16x3 student + f32 teacher"}[args.precision]
         out = {
@@ -243,18 +248,18 @@ def main():
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtype, "data": "synthetic",
-            "config": {"workload": "cfg3 full KD step: vit_small_patch16_224 teacher (embed 512/8 heads/4 layers) + "
-                                   "ResNet50-LSTM student (256/512/2-layer, refinement on), alpha=0.7 beta=0.2 gamma=0.1 T=4, "
+            "config": {"workload": f"{args.student} full KD step: vit_small_patch16_224 teacher (embed 512/8 heads/4 layers) + "
+                                   f"ResNet50-LSTM student ({'256/512/2' if args.student == 'cfg3' else '384/768/3'}-layer, refinement on), alpha=0.7 beta=0.2 gamma=0.1 T=4, "
                                    "V=5000, T=15, 224x224, clip 1.0 + AdamW every step",
                        "per_gpu_batch": args.batch, "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "hipgraph": not args.no_graph, "final_loss": round(loss["total_loss"], 5)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": measured_traffic(args.batch),
-                         "note": "whole step: 28.4 algorithmic GFLOP/image (SURVEY 8d) x batch / device time per step "
+                         "note": f"whole step: {gflop_img} algorithmic GFLOP/image (SURVEY 8d) x batch / device time per step "
                                  "(HIP events on the launch stream); denominator = fp32 MFMA peak for the exact-fp32 path, else the "
                                  "FLOP-weighted blend of the fp32 (teacher) and bf16 (student) MFMA peaks"},
         }
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and args.student == "cfg3":
             out["roofline"]["dominant_kernel"] = dominant_kernel(dev)
             # secondary measurements, same process: the reference's mixed-precision regime and BASELINE configs[1]
             if args.precision == "f32":
