@@ -45,7 +45,8 @@ if WORKLOAD == "cfg2":
         m.generate(images, 20)
         ops.gemm_raw = orig
 else:
-    student, teacher, projectors = build_kd_models(device="cuda")
+    dims = dict(embed_size=384, hidden_size=768, num_layers=3) if WORKLOAD == "cfg5" else {}
+    student, teacher, projectors = build_kd_models(device="cuda", **dims)
     tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=B, use_graph=False, precision=PREC, overlap_teacher=False)
     if PREC != "f32":
         ops._TUNED_BF16.clear()
