@@ -282,7 +282,11 @@ def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool,
     # eval mode: BatchNorm is a per-channel affine map -> folded into the conv epilogue (no second pass over the output);
     # same arithmetic as the two-pass form: fmaf(conv, scale, shift) + residual, then ReLU
     co = _eval_coeffs(bn)
-    y = ops.conv_fwd(x, w, conv.stride, conv.padding, scale=co[0], shift=co[1], residual=residual, relu=relu)
+    cin, cout = w.shape[3], w.shape[0]
+    if (cin % 32 == 0 or cin == 4) and cout % 4 == 0:       # shapes the LDS-DMA kernels take (every ResNet-50 conv)
+        y = ops.conv_fwd(x, w, conv.stride, conv.padding, scale=co[0], shift=co[1], residual=residual, relu=relu)
+    else:                                                   # two passes: conv, then the affine map + residual + ReLU
+        y = ops.scale_shift_act(ops.conv_fwd(x, w, conv.stride, conv.padding), co[0], co[1], residual, relu)
     return y, None, None, None
 
 
