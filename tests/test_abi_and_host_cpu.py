@@ -275,3 +275,19 @@ def test_gpu_transform_refuses_cpu():
         pytest.skip("GPU present")
     with pytest.raises(RuntimeError):
         GpuImageTransform(train=False, device="cpu")([np.zeros((10, 10, 3), np.uint8)])
+
+
+def test_bench_roofline_denominators():
+    """bench.py's roofline denominators: fp32 MFMA peak for the exact path; FLOP-weighted blend (teacher on the fp32
+    MFMA, student on the bf16 MFMA or 3 bf16 MFMAs per product) for the mixed-precision modes."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.GFLOP_PER_IMAGE == pytest.approx(b.GFLOP_TEACHER + b.GFLOP_STUDENT, abs=0.02)
+    assert b.mfma_peak("f32") == pytest.approx(157.3, rel=1e-3)
+    t = 9.80 / 157.3 + 18.61 / 2516.0
+    assert b.mfma_peak("bf16") == pytest.approx(28.41 / t, rel=1e-3)
+    assert b.mfma_peak("bf16") > b.mfma_peak("bf16x3") > b.mfma_peak("f32")
+    assert b.mfma_peak("f32", 20.95) == pytest.approx(157.3, rel=1e-3)      # cfg5 split, same peak for pure fp32
