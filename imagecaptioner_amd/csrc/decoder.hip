@@ -175,14 +175,17 @@ __global__ void lstm_cell_bwd_kernel(const float* __restrict__ dh_a, const float
   }
 }
 
-// ids[r] = first index of the maximum of logits[r][0..V) scaled by inv_temp (one wave per row)
+// ids[r] = torch.argmax(logits[r][0..V)): first index of the maximum, NaN counting as the largest value (one wave per
+// row).  A row that is all -inf (or all NaN) yields 0 like torch — never an out-of-range id: the next greedy step gathers
+// an embedding row with it.
+__device__ __forceinline__ bool amax_better(float v, float best) { return v > best || (v != v && best == best); }
 __global__ void argmax_rows_kernel(const float* __restrict__ x, long* __restrict__ ids, long rows, int V, long ld) {
   const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   for (long r = blockIdx.x * (long)wpb + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * wpb) {
     const float* xr = x + r * ld;
     float best = -INFINITY; int bi = V;
     // 16-byte loads, 4 of them in flight per lane (a 4-byte load per dependent compare left the wave latency-bound:
-    // 78 round trips per 5000-word row); indices grow with every step, strict > keeps the first maximum
+    // 78 round trips per 5000-word row); indices grow with every step, a strict comparison keeps the first maximum
     if ((ld & 3) == 0 && (V & 3) == 0) {
       const int V4 = V >> 2;
       int i = lane;
@@ -193,32 +196,33 @@ __global__ void argmax_rows_kernel(const float* __restrict__ x, long* __restrict
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int b = (i + 64 * u) * 4;
-          if (q[u].x > best) { best = q[u].x; bi = b; }
-          if (q[u].y > best) { best = q[u].y; bi = b + 1; }
-          if (q[u].z > best) { best = q[u].z; bi = b + 2; }
-          if (q[u].w > best) { best = q[u].w; bi = b + 3; }
+          if (amax_better(q[u].x, best)) { best = q[u].x; bi = b; }
+          if (amax_better(q[u].y, best)) { best = q[u].y; bi = b + 1; }
+          if (amax_better(q[u].z, best)) { best = q[u].z; bi = b + 2; }
+          if (amax_better(q[u].w, best)) { best = q[u].w; bi = b + 3; }
         }
       }
       for (; i < V4; i += 64) {
         const float4 q = reinterpret_cast<const float4*>(xr)[i];
         const int b = i * 4;
-        if (q.x > best) { best = q.x; bi = b; }
-        if (q.y > best) { best = q.y; bi = b + 1; }
-        if (q.z > best) { best = q.z; bi = b + 2; }
-        if (q.w > best) { best = q.w; bi = b + 3; }
+        if (amax_better(q.x, best)) { best = q.x; bi = b; }
+        if (amax_better(q.y, best)) { best = q.y; bi = b + 1; }
+        if (amax_better(q.z, best)) { best = q.z; bi = b + 2; }
+        if (amax_better(q.w, best)) { best = q.w; bi = b + 3; }
       }
     } else {
       for (int i = lane; i < V; i += 64) {
         const float v = xr[i];
-        if (v > best) { best = v; bi = i; }   // strict > keeps the first maximum within a lane
+        if (amax_better(v, best)) { best = v; bi = i; }
       }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ov = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+      const bool eq = ov == best || (ov != ov && best != best);
+      if (amax_better(ov, best) || (eq && oi < bi)) { best = ov; bi = oi; }
     }
-    if (lane == 0) ids[r] = bi;
+    if (lane == 0) ids[r] = bi < V ? bi : 0;
   }
 }
 

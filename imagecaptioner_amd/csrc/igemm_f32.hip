@@ -286,6 +286,14 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 tot[TM][TN];      // chunked accumulation (see igemm_f32_glds.hip): master sum of the folded MFMA chains
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  int chain = 0;
 
   if (nkt > 0) {
     fetch(0);
@@ -326,8 +334,23 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i], bv[cur][j], acc[i][j], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (++chain == p.chunk_tiles && kt + 1 < nkt) {
+      chain = 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          tot[i][j] += acc[i][j];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+    }
     __syncthreads();
   }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] += tot[i][j];
 
   // ---------------------------------------------------------------- epilogue
   // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).

@@ -274,6 +274,20 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // Chunked accumulation: one MFMA accumulator is a strictly sequential fp32 chain over k, whose rounding error grows
+  // with the chain length (measured: a K = 4608 chain is 4x further from fp64 than a K-blocked CPU GEMM, and that excess
+  // shows up 1.5-3x in every gradient behind the ResNet trunk).  Every p.chunk_tiles k-tiles (128 k by default; CPU
+  // GEMMs block K at ~256) the chain is folded into a master sum and restarted from zero.  Measured on the KD step
+  // (tools/diag_grads.py, profiles/r02_diag_grads_B{2,8}.log): gradient error vs fp64 relative to torch's CPU fp32 falls
+  // from 4.3-4.5x (refinement / decoder, B = 8) to 0.98x, trunk 1.10x -> 0.92x.
+  f32x16 tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  int chain = 0;
 
   // NBUF = 2: DMA of tile t+1 is issued at the top of iteration t (one compute phase to land).
   // NBUF = 3: DMA of tile t+2 is issued at the top of iteration t (two compute phases to land); the wait at the top of
@@ -323,7 +337,22 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
         }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (++chain == p.chunk_tiles && kt + 1 < nkt) {
+      chain = 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          tot[i][t] += acc[i][t];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+        }
+    }
   }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t];
 
   // ---------------------------------------------------------------- epilogue
   // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).

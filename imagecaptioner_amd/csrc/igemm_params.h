@@ -2,6 +2,7 @@
 // (igemm_f32.hip: exact fp32 MFMA; igemm_bf16.hip: bf16 / split-bf16 MFMA over the same fp32 operands in HBM).
 #pragma once
 #include "ick_common.h"
+#include <cstdlib>
 
 namespace ickg {
 
@@ -18,6 +19,7 @@ struct P {  // kernel parameters (by value)
   int stat_copies; long stat_stride;
   const float* col_scale;
   int no_ep_vec;   // IckGemm.tile bit 9: force the direct (dword) epilogue (A/B and diagnostics)
+  int chunk_tiles;   // fold the MFMA accumulators into the master sum every chunk_tiles k-tiles (0 = never)
   int ep_vec;   // LDS-staged 16-byte epilogue allowed (set by the launcher from the alignment of C / residual)
 };
 
@@ -78,6 +80,11 @@ inline int prepare(const IckGemm* d, int bk, P& p, int& nz, const char* who) {
   p.Nb = d->Nb; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
   p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad;
   nz = bo * p.batch_inner;
+  {
+    static const int env_chunk = [] { const char* e = getenv("ICK_KCHUNK"); return e ? atoi(e) : 0; }();   // A/B runs
+    const int kc = d->kchunk != 0 ? d->kchunk : (env_chunk != 0 ? env_chunk : 128);
+    p.chunk_tiles = kc > 0 ? (kc + bk - 1) / bk : 0;
+  }
   ICK_REQUIRE((d->stat_sum == nullptr) == (d->stat_sq == nullptr), "%s: stat_sum and stat_sq go together", who);
   if (p.splitk > 1) {
     ICK_REQUIRE(nz == 1, "%s: split-K and batching are exclusive", who);

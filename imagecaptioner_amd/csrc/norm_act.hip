@@ -225,19 +225,23 @@ __global__ void bn_train_apply_kernel(const float* __restrict__ x, const double*
 
 // BN backward pass 1: per channel sum(g) and sum(g * xhat), g = dy * (y > 0) when y != NULL.
 // Block = 256 threads as (ROWS x C4 lanes); each thread owns 4 channels, strides over rows; LDS combine, atomics out.
+// Accumulation: fp32 inside one trip of 4 rows, then fp64 per thread, fp64 in the LDS combine and fp64 atomics — the
+// reference's CPU batch_norm backward reduces in double (at::acc_type<float, /*is_cuda=*/false>), and these two sums are
+// differences of large terms (sum g is ~0 behind a mean-subtracting layer).
+struct d4 { double x, y, z, w; };
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                      const float* __restrict__ x, const float* __restrict__ mean,
-                                     const float* __restrict__ inv, float* __restrict__ sum_g,
-                                     float* __restrict__ sum_gx, long M, int C) {
+                                     const float* __restrict__ inv, double* __restrict__ sum_g,
+                                     double* __restrict__ sum_gx, long M, int C) {
   const int C4 = C >> 2;
   const int lanes = C4 < NT ? C4 : NT;     // threads along channels
   const int rows = NT / lanes;             // threads along rows
   const int tc = threadIdx.x % lanes, tr = threadIdx.x / lanes;
-  __shared__ float4 sh_g[NT], sh_x[NT];
+  __shared__ d4 sh_g[NT], sh_x[NT];
   for (int c4 = blockIdx.x * lanes + tc; c4 < C4; c4 += gridDim.x * lanes) {
     const float4 mu = reinterpret_cast<const float4*>(mean)[c4];
     const float4 iv = reinterpret_cast<const float4*>(inv)[c4];
-    float4 ag = make_float4(0, 0, 0, 0), ax = make_float4(0, 0, 0, 0);
+    d4 dg = {0, 0, 0, 0}, dx = {0, 0, 0, 0};
     if (tr < rows) {
       // 4 rows per trip: 12 independent 16-byte loads in flight per thread (one row per trip left the kernel
       // latency-bound at ~3.6 TB/s with 1.5 workgroups per CU)
@@ -252,6 +256,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
           xv[u] = reinterpret_cast<const float4*>(x)[o];
           if (y) yy[u] = reinterpret_cast<const float4*>(y)[o];
         }
+        float4 ag = make_float4(0, 0, 0, 0), ax = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (y) {
@@ -262,6 +267,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
           ax.x += g[u].x * (xv[u].x - mu.x) * iv.x; ax.y += g[u].y * (xv[u].y - mu.y) * iv.y;
           ax.z += g[u].z * (xv[u].z - mu.z) * iv.z; ax.w += g[u].w * (xv[u].w - mu.w) * iv.w;
         }
+        dg.x += ag.x; dg.y += ag.y; dg.z += ag.z; dg.w += ag.w;
+        dx.x += ax.x; dx.y += ax.y; dx.z += ax.z; dx.w += ax.w;
       }
       for (; m < M; m += step) {
         const long o = m * C4 + c4;
@@ -272,22 +279,22 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
           g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
         }
         const float4 xv = reinterpret_cast<const float4*>(x)[o];
-        ag.x += g.x; ag.y += g.y; ag.z += g.z; ag.w += g.w;
-        ax.x += g.x * (xv.x - mu.x) * iv.x; ax.y += g.y * (xv.y - mu.y) * iv.y;
-        ax.z += g.z * (xv.z - mu.z) * iv.z; ax.w += g.w * (xv.w - mu.w) * iv.w;
+        dg.x += g.x; dg.y += g.y; dg.z += g.z; dg.w += g.w;
+        dx.x += g.x * (xv.x - mu.x) * iv.x; dx.y += g.y * (xv.y - mu.y) * iv.y;
+        dx.z += g.z * (xv.z - mu.z) * iv.z; dx.w += g.w * (xv.w - mu.w) * iv.w;
       }
     }
-    sh_g[threadIdx.x] = ag; sh_x[threadIdx.x] = ax;
+    sh_g[threadIdx.x] = dg; sh_x[threadIdx.x] = dx;
     __syncthreads();
     if (tr == 0) {
       for (int r = 1; r < rows; ++r) {
-        const float4 a = sh_g[r * lanes + tc], b = sh_x[r * lanes + tc];
-        ag.x += a.x; ag.y += a.y; ag.z += a.z; ag.w += a.w;
-        ax.x += b.x; ax.y += b.y; ax.z += b.z; ax.w += b.w;
+        const d4 a = sh_g[r * lanes + tc], b = sh_x[r * lanes + tc];
+        dg.x += a.x; dg.y += a.y; dg.z += a.z; dg.w += a.w;
+        dx.x += b.x; dx.y += b.y; dx.z += b.z; dx.w += b.w;
       }
-      float* sg = sum_g + c4 * 4; float* sx = sum_gx + c4 * 4;
-      atomicAdd(sg + 0, ag.x); atomicAdd(sg + 1, ag.y); atomicAdd(sg + 2, ag.z); atomicAdd(sg + 3, ag.w);
-      atomicAdd(sx + 0, ax.x); atomicAdd(sx + 1, ax.y); atomicAdd(sx + 2, ax.z); atomicAdd(sx + 3, ax.w);
+      double* sg = sum_g + c4 * 4; double* sx = sum_gx + c4 * 4;
+      atomicAdd(sg + 0, dg.x); atomicAdd(sg + 1, dg.y); atomicAdd(sg + 2, dg.z); atomicAdd(sg + 3, dg.w);
+      atomicAdd(sx + 0, dx.x); atomicAdd(sx + 1, dx.y); atomicAdd(sx + 2, dx.z); atomicAdd(sx + 3, dx.w);
     }
     __syncthreads();
   }
@@ -298,14 +305,25 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                     const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ inv, const float* __restrict__ gamma,
-                                    const float* __restrict__ sum_g, const float* __restrict__ sum_gx, float invM,
+                                    const double* __restrict__ sum_g, const double* __restrict__ sum_gx, double invM,
                                     float* __restrict__ dx, float* __restrict__ gout, long total4, int C4,
                                     int use_batch_stats, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   // the parameter gradients are the two reductions themselves: dgamma += sum(g*xhat), dbeta += sum(g)
   if (dgamma && blockIdx.x == 0)
-    for (int c = threadIdx.x; c < 4 * C4; c += blockDim.x) { dgamma[c] += sum_gx[c]; dbeta[c] += sum_g[c]; }
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C4);
+    for (int c = threadIdx.x; c < 4 * C4; c += blockDim.x) { dgamma[c] += (float)sum_gx[c]; dbeta[c] += (float)sum_g[c]; }
+  // the grid stride is a multiple of C4 (launcher), so a thread's 4 channels never change: per-channel terms once
+  const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  const int c = (int)(i0 % C4);
+  const float4 ga = reinterpret_cast<const float4*>(gamma)[c];
+  const float4 iv = reinterpret_cast<const float4*>(inv)[c];
+  float4 mu = make_float4(0, 0, 0, 0), mg = mu, mx = mu;
+  if (use_batch_stats) {
+    mu = reinterpret_cast<const float4*>(mean)[c];
+    const double* sg = sum_g + 4 * c; const double* sx = sum_gx + 4 * c;
+    mg = make_float4((float)(sg[0] * invM), (float)(sg[1] * invM), (float)(sg[2] * invM), (float)(sg[3] * invM));
+    mx = make_float4((float)(sx[0] * invM), (float)(sx[1] * invM), (float)(sx[2] * invM), (float)(sx[3] * invM));
+  }
+  for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
     float4 g = reinterpret_cast<const float4*>(dy)[i];
     if (y) {
       const float4 yy = reinterpret_cast<const float4*>(y)[i];
@@ -313,18 +331,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
       g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
     }
     if (gout) reinterpret_cast<float4*>(gout)[i] = g;
-    const float4 ga = reinterpret_cast<const float4*>(gamma)[c];
-    const float4 iv = reinterpret_cast<const float4*>(inv)[c];
     float4 o;
     if (use_batch_stats) {
       const float4 xv = reinterpret_cast<const float4*>(x)[i];
-      const float4 mu = reinterpret_cast<const float4*>(mean)[c];
-      const float4 sg = reinterpret_cast<const float4*>(sum_g)[c];
-      const float4 sx = reinterpret_cast<const float4*>(sum_gx)[c];
-      o.x = ga.x * iv.x * (g.x - sg.x * invM - (xv.x - mu.x) * iv.x * sx.x * invM);
-      o.y = ga.y * iv.y * (g.y - sg.y * invM - (xv.y - mu.y) * iv.y * sx.y * invM);
-      o.z = ga.z * iv.z * (g.z - sg.z * invM - (xv.z - mu.z) * iv.z * sx.z * invM);
-      o.w = ga.w * iv.w * (g.w - sg.w * invM - (xv.w - mu.w) * iv.w * sx.w * invM);
+      o.x = ga.x * iv.x * (g.x - mg.x - (xv.x - mu.x) * iv.x * mx.x);
+      o.y = ga.y * iv.y * (g.y - mg.y - (xv.y - mu.y) * iv.y * mx.y);
+      o.z = ga.z * iv.z * (g.z - mg.z - (xv.z - mu.z) * iv.z * mx.z);
+      o.w = ga.w * iv.w * (g.w - mg.w - (xv.w - mu.w) * iv.w * mx.w);
     } else {
       o = make_float4(ga.x * iv.x * g.x, ga.y * iv.y * g.y, ga.z * iv.z * g.z, ga.w * iv.w * g.w);
     }
@@ -619,7 +632,7 @@ int ick_scale_shift_act(const float* x, const float* scale, const float* shift, 
 }
 
 int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                      float* sum_g, float* sum_gx, long M, int C, void* stream) {
+                      double* sum_g, double* sum_gx, long M, int C, void* stream) {
   ICK_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && C % 4 == 0 && M > 0, "ick_bn_bwd_reduce: bad arguments");
   const int C4 = C / 4;
   const int lanes = C4 < NT ? C4 : NT;
@@ -634,13 +647,19 @@ int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const flo
 }
 
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                     const float* gamma, const float* sum_g, const float* sum_gx, float* dx, float* g_out, long M, int C,
+                     const float* gamma, const double* sum_g, const double* sum_gx, float* dx, float* g_out, long M, int C,
                      int use_batch_stats, float* dgamma, float* dbeta, void* stream) {
   ICK_REQUIRE(dy && x && mean && invstd && gamma && dx && C % 4 == 0 && M > 0, "ick_bn_bwd_apply: bad arguments");
   ICK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "ick_bn_bwd_apply: dgamma and dbeta go together");
-  const long total4 = M * (C / 4);
-  ICK_LAUNCH(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, sum_g,
-                     sum_gx, 1.0f / (float)M, dx, g_out, total4, C / 4, use_batch_stats, dgamma, dbeta);
+  ICK_REQUIRE(!use_batch_stats || (sum_g && sum_gx), "ick_bn_bwd_apply: batch statistics need the two sums");
+  const int C4 = C / 4;
+  ICK_REQUIRE(C4 <= NT ? NT % C4 == 0 : C4 % NT == 0, "ick_bn_bwd_apply: C/4=%d must divide %d or be a multiple of it", C4, NT);
+  const long total4 = M * C4;
+  int grid = grid_for(total4);
+  const int q = C4 > NT ? C4 / NT : 1;          // grid * NT must be a multiple of C4: a thread keeps its channels
+  grid = (grid + q - 1) / q * q;
+  ICK_LAUNCH(bn_bwd_apply_kernel, dim3(grid), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, sum_g,
+                     sum_gx, 1.0 / (double)M, dx, g_out, total4, C4, use_batch_stats, dgamma, dbeta);
   return ick::launch_status("bn_bwd_apply");
 }
 

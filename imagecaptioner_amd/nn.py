@@ -247,11 +247,22 @@ class _Arena:
         return v
 
 
+_PARAM_GENERATION = [0]
+
+
+def bump_param_generation() -> None:
+    """Called by whoever changes parameters / BatchNorm buffers through RAW POINTERS (graph replays of the train step,
+    the flat AdamW pass, bn_train_apply): those writes do not touch torch's version counters, so caches keyed on
+    (data_ptr, _version) alone would go stale — e.g. the eval-mode BatchNorm coefficients between two validations."""
+    _PARAM_GENERATION[0] += 1
+
+
 def _eval_coeffs(bn: BatchNorm2d) -> torch.Tensor:
     """(scale, shift) of an eval-mode BatchNorm, cached on the module until one of its four tensors changes (in-place
-    version counters / storage), so that repeated inference does not relaunch 53 tiny kernels per forward."""
+    version counters / storage) or a raw-pointer writer announces itself (bump_param_generation), so that repeated
+    inference does not relaunch 53 tiny kernels per forward."""
     ts = (bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple((t.data_ptr(), t._version) for t in ts)
+    key = (_PARAM_GENERATION[0],) + tuple((t.data_ptr(), t._version) for t in ts)
     cached = getattr(bn, "_ick_eval_co", None)
     if cached is None or cached[0] != key:
         cached = (key, ops.bn_eval_coeffs(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps))
@@ -327,6 +338,60 @@ def _block_trainable(blk: Bottleneck) -> bool:
     return any(p.requires_grad for p in blk.parameters())
 
 
+def bottleneck_forward(blk: Bottleneck, x, train: bool, arena=None, counters=None):
+    """One torchvision Bottleneck on NHWC activations: out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + identity).
+    Returns (out, rec); rec holds what bottleneck_backward needs (raw conv outputs, activations, saved statistics)."""
+    cb = lambda t, c, b, relu, res: conv_bn(t, c, b, relu, res, train, arena=arena, counters=counters)
+    a1, r1, m1, i1 = cb(x, blk.conv1, blk.bn1, True, None)
+    a2, r2, m2, i2 = cb(a1, blk.conv2, blk.bn2, True, None)
+    if blk.downsample is not None:
+        idt, rd, md, idv = cb(x, blk.downsample[0], blk.downsample[1], False, None)
+    else:
+        idt, rd, md, idv = x, None, None, None
+    out, r3, m3, i3 = cb(a2, blk.conv3, blk.bn3, True, idt)
+    return out, dict(x=x, a1=a1, r1=r1, m1=m1, i1=i1, a2=a2, r2=r2, m2=m2, i2=i2, out=out, r3=r3, m3=m3, i3=i3, rd=rd, md=md,
+                     idv=idv)
+
+
+def bottleneck_backward(blk: Bottleneck, r: dict, d, need_in: bool, sums_arena=None):
+    """Backward of bottleneck_forward (train-mode BatchNorm): d = dL/d out; accumulates every weight / BatchNorm gradient
+    into .grad and returns dL/dx (None unless need_in)."""
+    def bnb(dyv, ymask, raw, mean, inv, bn, want_g=False):
+        C = bn.weight.numel()
+        return ops.bn_bwd(dyv, ymask, raw, mean, inv, bn.weight, grad_buf(bn.weight) if bn.weight.requires_grad else None,
+                          grad_buf(bn.bias) if bn.weight.requires_grad else None, want_g, True,
+                          sums=sums_arena.take(2, C) if sums_arena is not None else None)
+
+    def wgrad(conv, dyv, xin):
+        if conv.weight.requires_grad:
+            ops.conv_wgrad(dyv, xin, conv.packed_grad(), conv.stride, conv.padding)
+
+    dx3, g3 = bnb(d, r["out"], r["r3"], r["m3"], r["i3"], blk.bn3, want_g=True)
+    wgrad(blk.conv3, dx3, r["a2"])
+    da2 = ops.conv_dgrad(dx3, blk.conv3.packed(), r["a2"].shape[1:3], 1, 0)
+    dx2, _ = bnb(da2, r["a2"], r["r2"], r["m2"], r["i2"], blk.bn2)
+    wgrad(blk.conv2, dx2, r["a1"])
+    da1 = ops.conv_dgrad(dx2, blk.conv2.packed(), r["a1"].shape[1:3], blk.conv2.stride, 1)
+    dx1, _ = bnb(da1, r["a1"], r["r1"], r["m1"], r["i1"], blk.bn1)
+    wgrad(blk.conv1, dx1, r["x"])
+    hw = r["x"].shape[1:3]
+    if blk.downsample is None:
+        return ops.conv_dgrad(dx1, blk.conv1.packed(), hw, 1, 0, residual=g3) if need_in else None
+    dsc, dsb = blk.downsample[0], blk.downsample[1]
+    dxd, _ = bnb(g3, None, r["rd"], r["md"], r["idv"], dsb)
+    wgrad(dsc, dxd, r["x"])
+    if not need_in:
+        return None
+    dxi = ops.conv_dgrad(dx1, blk.conv1.packed(), hw, 1, 0)
+    ops.conv_dgrad(dxd, dsc.packed(), hw, dsc.stride, 0, out=dxi, accumulate=True)
+    return dxi
+
+
+def _bn_channels(blocks) -> int:
+    return sum(b.bn1.weight.numel() + b.bn2.weight.numel() + b.bn3.weight.numel() +
+               (b.downsample[1].weight.numel() if b.downsample is not None else 0) for b in blocks)
+
+
 class ResNetTrunkFn(Function):
     """The whole ResNet-50 trunk as ONE autograd node with a hand-scheduled backward: conv raw outputs and block
     outputs are kept only for blocks at/after the first trainable one; residual adds, ReLU masks and BatchNorm
@@ -343,80 +408,36 @@ class ResNetTrunkFn(Function):
         blocks: List[Bottleneck] = [b for li in (4, 5, 6, 7) for b in resnet[li]]
         arena = counters = None
         if train:
-            nch = 64 + sum(b.bn1.weight.numel() + b.bn2.weight.numel() + b.bn3.weight.numel() +
-                           (b.downsample[1].weight.numel() if b.downsample is not None else 0) for b in blocks)
-            arena, counters = _Arena(2 * nch * 8, torch.float64, images.device), []   # up to 8 accumulator copies per BN (ops.stat_copies)
-        cb = lambda x, c, b, relu, res: conv_bn(x, c, b, relu, res, train, arena=arena, counters=counters)
+            # up to 8 accumulator copies per BatchNorm (ops.stat_copies)
+            arena, counters = _Arena(2 * (64 + _bn_channels(blocks)) * 8, torch.float64, images.device), []
         y, _, _, _ = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters)
         y = ops.maxpool3x3s2(y)
         first = next((i for i, b in enumerate(blocks) if _block_trainable(b)), len(blocks))
         want_bwd = any(ctx.needs_input_grad) and first < len(blocks)   # (forward itself always runs in no-grad mode)
+        if want_bwd and not train:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not needed by the KD step")
         recs = []
         for i, blk in enumerate(blocks):
-            keep = want_bwd and i >= first
-            a1, r1, m1, i1 = cb(y, blk.conv1, blk.bn1, True, None)
-            a2, r2, m2, i2 = cb(a1, blk.conv2, blk.bn2, True, None)
-            if blk.downsample is not None:
-                idt, rd, md, idv = cb(y, blk.downsample[0], blk.downsample[1], False, None)
-            else:
-                idt, rd, md, idv = y, None, None, None
-            out, r3, m3, i3 = cb(a2, blk.conv3, blk.bn3, True, idt)
-            if keep:
-                recs.append(dict(x=y, a1=a1, r1=r1, m1=m1, i1=i1, a2=a2, r2=r2, m2=m2, i2=i2, out=out, r3=r3, m3=m3,
-                                 i3=i3, rd=rd, md=md, idv=idv))
-            y = out
+            y, rec = bottleneck_forward(blk, y, train, arena, counters)
+            if want_bwd and i >= first:
+                recs.append(rec)
         if counters:
             torch._foreach_add_(counters, 1)       # all num_batches_tracked counters in one launch (bookkeeping)
-        ctx.blocks, ctx.first, ctx.recs, ctx.train = blocks, first, recs, train
+        ctx.blocks, ctx.first, ctx.recs = blocks, first, recs
         Nb, H, W, C = y.shape
         return y.view(Nb, H * W, C)                                  # (B,49,2048): NHWC is already "permute(0,2,1)"
 
     @staticmethod
     def backward(ctx, dy):
-        blocks, first, recs, train = ctx.blocks, ctx.first, ctx.recs, ctx.train
+        blocks, first, recs = ctx.blocks, ctx.first, ctx.recs
         if not recs:
-            return (None,) * (3 + sum(1 for b in blocks for _ in b.parameters()) + 3)
+            return (None,) * len(ctx.needs_input_grad)
         d = _c(dy).view(recs[-1]["out"].shape)
-        nch = sum(b.bn1.weight.numel() + b.bn2.weight.numel() + b.bn3.weight.numel() +
-                  (b.downsample[1].weight.numel() if b.downsample is not None else 0) for b in blocks[first:])
-        sums_arena = _Arena(2 * nch, torch.float32, d.device)
+        sums_arena = _Arena(2 * _bn_channels(blocks[first:]), torch.float64, d.device)
         for i in range(len(blocks) - 1, first - 1, -1):
-            blk, r = blocks[i], recs[i - first]
-            need_in = i > first
-
-            def bnb(dyv, ymask, raw, mean, inv, bn, want_g=False):
-                if train:
-                    return ops.bn_bwd(dyv, ymask, raw, mean, inv, bn.weight, grad_buf(bn.weight) if bn.weight.requires_grad else None,
-                                      grad_buf(bn.bias) if bn.weight.requires_grad else None, want_g, True,
-                                      sums=sums_arena.take(2, bn.weight.numel()))
-                raise NotImplementedError("backward through eval-mode BatchNorm is not needed by the KD step")
-
-            def wgrad(conv, dyv, xin):
-                if conv.weight.requires_grad:
-                    ops.conv_wgrad(dyv, xin, conv.packed_grad(), conv.stride, conv.padding)
-
-            dx3, g3 = bnb(d, r["out"], r["r3"], r["m3"], r["i3"], blk.bn3, want_g=True)
-            wgrad(blk.conv3, dx3, r["a2"])
-            da2 = ops.conv_dgrad(dx3, blk.conv3.packed(), r["a2"].shape[1:3], 1, 0)
-            dx2, _ = bnb(da2, r["a2"], r["r2"], r["m2"], r["i2"], blk.bn2)
-            wgrad(blk.conv2, dx2, r["a1"])
-            da1 = ops.conv_dgrad(dx2, blk.conv2.packed(), r["a1"].shape[1:3], blk.conv2.stride, 1)
-            dx1, _ = bnb(da1, r["a1"], r["r1"], r["m1"], r["i1"], blk.bn1)
-            wgrad(blk.conv1, dx1, r["x"])
-            hw = r["x"].shape[1:3]
-            if blk.downsample is None:
-                d = ops.conv_dgrad(dx1, blk.conv1.packed(), hw, 1, 0, residual=g3) if need_in else None
-            else:
-                dsc, dsb = blk.downsample[0], blk.downsample[1]
-                dxd, _ = bnb(g3, None, r["rd"], r["md"], r["idv"], dsb)
-                wgrad(dsc, dxd, r["x"])
-                if need_in:
-                    d = ops.conv_dgrad(dx1, blk.conv1.packed(), hw, 1, 0)
-                    ops.conv_dgrad(dxd, dsc.packed(), hw, dsc.stride, 0, out=d, accumulate=True)
-                else:
-                    d = None
+            d = bottleneck_backward(blocks[i], recs[i - first], d, i > first, sums_arena)
             recs[i - first] = None                                   # free this block's activations
-        return (None,) * (3 + len(ctx.needs_input_grad) - 3)
+        return (None,) * len(ctx.needs_input_grad)
 
 
 def resnet_trunk(images, resnet: nn.Sequential, train: bool):

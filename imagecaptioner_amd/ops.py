@@ -45,6 +45,7 @@ def zeros(*shape, device=None) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- raw GEMM
 _FORCE_TILE = [0]       # tools/profile_step_gemms.py sweeps tile shapes through this
+_KCHUNK = [0]           # diagnostics: IckGemm.kchunk of every descriptor (0 = library default 128, -1 = one chain over K)
 _TILE_OR = [0]          # diagnostics: bits OR-ed into every descriptor's tile field (512 = direct epilogue)
 
 
@@ -105,12 +106,13 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
              strides: Tuple[int, int, int, int, int, int] = (0, 0, 0, 0, 0, 0), splitk: int = 1,
              accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
              conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0,
-             col_scale: Optional[int] = None) -> None:
+             col_scale: Optional[int] = None, kchunk: int = 0) -> None:
     d = IckGemm()
     d.A, d.B, d.C = A, B, C
     d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
     d.stat_copies, d.stat_stride = stat_copies, stat_stride
     d.col_scale = col_scale
+    d.kchunk = kchunk or _KCHUNK[0]
     d.op, d.act = op, act
     d.M, d.N, d.K = M, N, K
     d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
@@ -420,7 +422,7 @@ def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batc
     C = x.shape[-1]
     M = x.numel() // C
     if sums is None:
-        sums = zeros(2, C, device=x.device)
+        sums = torch.zeros(2, C, dtype=torch.float64, device=x.device)
     check(_lib.lib().ick_bn_bwd_reduce(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                        sums[0].data_ptr(), sums[1].data_ptr(), M, C, _st()), "ick_bn_bwd_reduce")
     dx = torch.empty_like(x)
@@ -618,6 +620,13 @@ def adamw_step(p, g, m, v, lr, betas, eps, wd, step, norm=None, max_norm=1.0, in
     check(_lib.lib().ick_adamw_step(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1],
                                     eps, wd, step, _ptr(norm), max_norm, inv_scale, int(write_clipped), _ptr(hyper),
                                     _ptr(scaler), _st()), "ick_adamw_step")
+
+
+def adam_bias_correction(applied_steps: torch.Tensor, scaler: Optional[torch.Tensor], betas, hyper: torch.Tensor) -> None:
+    """t = ++applied_steps unless the GradScaler found inf/nan; hyper[g][1..2] = 1-beta1^t, 1-beta2^t for every row g."""
+    assert applied_steps.dtype == torch.int64 and hyper.is_contiguous()
+    check(_lib.lib().ick_adam_bias_correction(applied_steps.data_ptr(), _ptr(scaler), betas[0], betas[1], hyper.data_ptr(),
+                                              hyper.shape[0], hyper.shape[1], _st()), "ick_adam_bias_correction")
 
 
 def loss_scale_check(norms: torch.Tensor, state: torch.Tensor) -> None:

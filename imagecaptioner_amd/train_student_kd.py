@@ -30,18 +30,20 @@ from . import ops
 from .distillation_utils import DistillationLoss, TeacherWrapper
 
 
-def cosine_warm_restarts_factor(epoch: float, T_0: int = 5, T_mult: int = 2) -> float:
-    """(1 + cos(pi * T_cur / T_i)) / 2 of torch.optim.lr_scheduler.CosineAnnealingWarmRestarts.step(epoch), closed form
-    for fractional epochs; a group's LR is eta_min + (base_lr - eta_min) * factor."""
+def cosine_warm_restarts_state(epoch: float, T_0: int = 5, T_mult: int = 2) -> Tuple[float, float]:
+    """(T_cur, T_i) of torch.optim.lr_scheduler.CosineAnnealingWarmRestarts after .step(epoch), closed form for
+    fractional epochs (reference: stepped with epoch + batch_idx / len(loader), train_student_kd.py:236,:303)."""
     if epoch >= T_0:
         if T_mult == 1:
-            t_cur, t_i = epoch % T_0, T_0
-        else:
-            n = int(math.log(epoch / T_0 * (T_mult - 1) + 1, T_mult))
-            t_cur = epoch - T_0 * (T_mult ** n - 1) / (T_mult - 1)
-            t_i = T_0 * T_mult ** n
-    else:
-        t_cur, t_i = epoch, T_0
+            return epoch % T_0, T_0
+        n = int(math.log(epoch / T_0 * (T_mult - 1) + 1, T_mult))
+        return epoch - T_0 * (T_mult ** n - 1) / (T_mult - 1), T_0 * T_mult ** n
+    return epoch, T_0
+
+
+def cosine_warm_restarts_factor(epoch: float, T_0: int = 5, T_mult: int = 2) -> float:
+    """(1 + cos(pi * T_cur / T_i)) / 2; a group's LR is eta_min + (base_lr - eta_min) * factor."""
+    t_cur, t_i = cosine_warm_restarts_state(epoch, T_0, T_mult)
     return (1 + math.cos(math.pi * t_cur / t_i)) / 2
 
 
@@ -130,14 +132,26 @@ class KDTrainer:
                                 ("refine", other), ("projector", proj_params)], self.device)
         self.group_lr_mult = {"encoder": 0.1, "decoder": 1.0, "refine": 1.0, "projector": 1.0}
         self.hyper = torch.zeros(4, 4, dtype=torch.float32, device=self.device)     # per group: lr, 1-b1^t, 1-b2^t, -
-        self.hyper_host = torch.zeros(4, 4, dtype=torch.float32).pin_memory() if self.device.type == "cuda" else torch.zeros(4, 4)
+        # the LR column is uploaded per optimizer step from a RING of pinned buffers, each guarded by an event: the host
+        # runs ahead of the stream (train_step never synchronises), so one buffer would be overwritten while earlier
+        # copies are still queued.  The bias corrections are computed ON DEVICE from a device-side count of APPLIED
+        # steps (ick_adam_bias_correction inside the optimizer graph): a step the GradScaler skips does not advance t,
+        # exactly like torch's scaler.step(optimizer).
+        cuda = self.device.type == "cuda"
+        self._hyper_ring = [torch.zeros(4, 4, dtype=torch.float32).pin_memory() if cuda else torch.zeros(4, 4) for _ in range(8)]
+        self._hyper_events = [None] * len(self._hyper_ring)
+        self._hyper_slot = 0
+        self.applied_steps_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.norms = torch.zeros(2, dtype=torch.float32, device=self.device)        # [student norm, projector norm]
         self.ws = torch.zeros(1024, dtype=torch.float32, device=self.device)
-        self.step_count = 0
+        self.step_count = 0          # optimizer windows completed on the host side (applied_steps() excludes skipped ones)
         self.batch_idx = 0
         self.epoch = 0
         self.drop_step = torch.zeros(1, dtype=torch.int64, device=self.device)
         ops.set_dropout_step_counter(self.drop_step)
+        if self.world > 1:           # every rank draws its own dropout masks on its shard
+            rank = torch.distributed.get_rank(process_group)
+            hnn.manual_seed(hnn._seed_state["seed"] ^ (0x9E3779B1 * (rank + 1) & 0xFFFFFFFF))
         self.images = torch.zeros(batch_size, 3, 224, 224, dtype=torch.float32, device=self.device)
         self.captions = torch.zeros(t_plus_1, batch_size, dtype=torch.int64, device=self.device)
         self.scaler = None
@@ -199,6 +213,7 @@ class KDTrainer:
             ops.grad_norm(f.grad[pa:pb], self.ws, self.norms[1:2])
         if self.scaler is not None:
             ops.loss_scale_check(self.norms, self.scaler)
+        ops.adam_bias_correction(self.applied_steps_dev, self.scaler, self.betas, self.hyper)
         for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
             a, b = f.segment(name)
             if b <= a:
@@ -212,16 +227,27 @@ class KDTrainer:
             f.grad.zero_()                               # optimizer.zero_grad() (reference :299)
 
     def _update_hyper(self):
-        t = self.step_count + 1
         ep = self.epoch + self.batch_idx / max(1, self.batches_per_epoch)
+        slot = self._hyper_slot
+        self._hyper_slot = (slot + 1) % len(self._hyper_ring)
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()       # the copy that last read this pinned buffer has executed
+        host = self._hyper_ring[slot]
         for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
             # the scheduler is stepped AFTER optimizer.step() in the reference (:299-303): step k uses the LR set at k-1
             base = self.lr * self.group_lr_mult[name]
-            self.hyper_host[gi, 0] = self.eta_min + (base - self.eta_min) * self._f_now
-            self.hyper_host[gi, 1] = 1.0 - self.betas[0] ** t
-            self.hyper_host[gi, 2] = 1.0 - self.betas[1] ** t
-        self.hyper.copy_(self.hyper_host, non_blocking=True)
+            host[gi, 0] = self.eta_min + (base - self.eta_min) * self._f_now
+        # only the LR column travels (strided view of the device tensor): columns 1-2 belong to the device-side counter
+        self.hyper[:, 0].copy_(host[:, 0], non_blocking=True)
+        if self.device.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+            self._hyper_events[slot] = ev
         self._f_next = cosine_warm_restarts_factor(ep)
+
+    def applied_steps(self) -> int:
+        """optimizer steps actually applied (synchronises): excludes the ones the GradScaler skipped on inf / nan."""
+        return int(self.applied_steps_dev.item())
 
     _f_now = 1.0
     _f_next = 1.0
@@ -231,6 +257,7 @@ class KDTrainer:
         bufs = [(b, b.clone()) for b in self.student.buffers()]       # warm-up must not count as training steps
         if self.scaler is not None:
             bufs.append((self.scaler, self.scaler.clone()))
+        bufs.append((self.applied_steps_dev, self.applied_steps_dev.clone()))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -253,8 +280,7 @@ class KDTrainer:
 
     def _optimizer_dry(self):
         """warm-up call of the optimizer kernels that leaves parameters untouched (lr = 0, moments restored)."""
-        self.hyper.zero_()
-        self.hyper[:, 1:3] = 1.0
+        self.hyper.zero_()           # lr = 0 (the bias-correction columns are rewritten by the device-side counter)
         m, v = self.flat.exp_avg.clone(), self.flat.exp_avg_sq.clone()
         wd, self.wd = self.wd, 0.0
         self._optimizer()
@@ -271,9 +297,12 @@ class KDTrainer:
         if captions is not None:
             self.captions.copy_(captions, non_blocking=True)
         self.student.train()
+        hnn.bump_param_generation()      # this step rewrites weights and BatchNorm running statistics by raw pointer
         if self.use_graph and self.g_fb is None:
             self._capture()
-        boundary = (self.micro_idx + 1) % self.accumulation_steps == 0
+        # window boundary by the per-epoch batch index, as the reference counts it (:290): a window cut short by the end
+        # of an epoch keeps its gradients and completes in the next epoch
+        boundary = (self.batch_idx + 1) % self.accumulation_steps == 0
         if boundary:
             self._update_hyper()
         if self.use_graph:
@@ -313,17 +342,18 @@ class KDTrainer:
         """torch.optim.AdamW-compatible state dict rebuilt from the flat moment buffers, so that
         `AdamW(groups).load_state_dict(...)` of a reference-side tool accepts it."""
         where = {id(p): (o, n) for p, o, n in self.flat.metas}
+        applied = self.applied_steps()
         state, groups, idx = {}, [], 0
         lr_mult = (0.1, 1.0, 1.0)
         for gi, plist in enumerate(self._optimizer_param_groups()):
             ids = []
             for p in plist:
-                if id(p) in where and self.step_count > 0:
+                if id(p) in where and applied > 0:
                     o, n = where[id(p)]
                     shape4 = p.dim() == 4
                     view = (lambda flat: flat[o:o + n].view(p.shape[0], p.shape[2], p.shape[3], p.shape[1]).permute(0, 3, 1, 2)
                             if shape4 else flat[o:o + n].view(p.shape))
-                    state[idx] = {"step": torch.tensor(float(self.step_count)), "exp_avg": view(self.flat.exp_avg).clone(),
+                    state[idx] = {"step": torch.tensor(float(applied)), "exp_avg": view(self.flat.exp_avg).clone(),
                                   "exp_avg_sq": view(self.flat.exp_avg_sq).clone()}
                 ids.append(idx)
                 idx += 1
@@ -336,7 +366,8 @@ class KDTrainer:
 
     def scheduler_state_dict(self) -> dict:
         ep = self.epoch + self.batch_idx / max(1, self.batches_per_epoch)
-        return {"T_0": 5, "T_i": 5, "T_mult": 2, "eta_min": self.eta_min, "T_cur": ep, "last_epoch": ep,
+        t_cur, t_i = cosine_warm_restarts_state(ep)
+        return {"T_0": 5, "T_i": t_i, "T_mult": 2, "eta_min": self.eta_min, "T_cur": t_cur, "last_epoch": ep,
                 "base_lrs": [self.lr * 0.1, self.lr, self.lr]}
 
     def checkpoint(self, epoch: int, val_loss: float = float("nan"), val_bleu: float = float("nan"),

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ICK_ABI_VERSION 2
+#define ICK_ABI_VERSION 3
 
 const char* ick_last_error(void);
 int ick_abi_version(void);
@@ -73,6 +73,7 @@ typedef struct IckGemm {
   int32_t stat_copies;                          /* <= 1: one accumulator row; R > 1: stat_sum/stat_sq are [R][stat_stride] and the row-tile t of the grid adds into copy t % R (spreads the fp64 atomics of large-M convolutions over R x as many cache lines; consumers sum the copies) */
   int64_t stat_stride;                          /* elements between two copies (>= N) */
   const float* col_scale;                       /* [N] or NULL: C = act(col_scale[n] * alpha*sum + bias[n] ...) — eval-mode BatchNorm folded into the conv epilogue (scale = gamma/sqrt(var+eps), bias = shift); needs N %% 4, ldc %% 4, no split-K */
+  int32_t kchunk;                               /* fp32 kernels: k elements one MFMA accumulator chain sums before it is folded into a master accumulator (bounds the rounding error of long-K products the way a K-blocked CPU GEMM does); 0 = library default (128), < 0 = one chain over all of K */
 } IckGemm;
 
 int ick_gemm_f32(const IckGemm* desc, void* stream);
@@ -124,9 +125,9 @@ int ick_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 int ick_scale_shift_act(const float* x, const float* scale, const float* shift, const float* residual, float* y,
                         int64_t M, int C, int relu, void* stream);                          /* y = [relu](x*scale+shift [+ residual]) */
 int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                      float* sum_g, float* sum_gx, int64_t M, int C, void* stream);          /* += sum(g), sum(g*xhat); g = dy*(y>0) if y */
+                      double* sum_g, double* sum_gx, int64_t M, int C, void* stream);        /* += sum(g), sum(g*xhat) in fp64 (the reference's CPU batch_norm backward reduces in double); g = dy*(y>0) if y */
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                     const float* gamma, const float* sum_g, const float* sum_gx, float* dx, float* g_out,
+                     const float* gamma, const double* sum_g, const double* sum_gx, float* dx, float* g_out,
                      int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, void* stream); /* dgamma/dbeta (optional) += the two sums */
 int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, const float* residual,
@@ -202,6 +203,12 @@ int ick_grad_norm(const float* x, int64_t n, float* workspace, float* norm_out, 
 int ick_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                    float weight_decay, int step, const float* norm, float max_norm, float inv_scale, int write_clipped,
                    const float* hyper, const float* scaler, void* stream);
+/* Adam's step count as device state: *applied_steps += 1 unless scaler (GradScaler state, optional) reports found_inf —
+ * torch's scaler.step(optimizer) leaves state['step'] untouched on a skipped step — then hyper[g*stride + 1] = 1 - beta1^t,
+ * hyper[g*stride + 2] = 1 - beta2^t for g < n_groups (the rows ick_adamw_step reads), so a replayed hipGraph needs no
+ * host-computed bias correction. */
+int ick_adam_bias_correction(int64_t* applied_steps, const float* scaler, double beta1, double beta2, float* hyper,
+                             int n_groups, int stride, void* stream);
 /* torch.amp.GradScaler (train_student_kd.py:239,288-298) as device state {scale, 1/scale, found_inf, good_steps}:
  * _check marks found_inf from the norms of the scaled gradients (unscale_), ick_adamw_step(scaler=state) unscales and
  * skips on found_inf (scaler.step), _update applies growth / backoff (scaler.update). */

@@ -1,0 +1,17 @@
+"""TEST INFRASTRUCTURE.  Which gradient slices tests/golden/kd_step_cfg3_B16.npz holds (shared by the generator
+oracle/make_goldens.py, which needs /root/reference, and by tests/test_kd_step_b16_gpu.py, which must not)."""
+import numpy as np
+
+B16_KEYS = {   # tensor -> slice kept in the fixture (a few thousand values each, spread over the whole tensor)
+    "encoder.resnet.6.0.conv1.weight": np.s_[::4, ::8, 0, 0], "encoder.resnet.6.0.conv2.weight": np.s_[::8, ::8],
+    "encoder.resnet.6.0.bn1.weight": np.s_[:], "encoder.resnet.6.0.downsample.0.weight": np.s_[::16, ::8, 0, 0],
+    "encoder.resnet.6.3.conv2.weight": np.s_[::8, ::8], "encoder.resnet.6.5.conv3.weight": np.s_[::16, ::4, 0, 0],
+    "encoder.resnet.6.5.bn3.bias": np.s_[:], "encoder.resnet.7.0.conv1.weight": np.s_[::8, ::16, 0, 0],
+    "encoder.resnet.7.0.conv2.weight": np.s_[::16, ::16], "encoder.resnet.7.0.downsample.0.weight": np.s_[::32, ::16, 0, 0],
+    "encoder.resnet.7.1.conv2.weight": np.s_[::16, ::16], "encoder.resnet.7.2.conv3.weight": np.s_[::32, ::8, 0, 0],
+    "encoder.resnet.7.2.bn3.weight": np.s_[:], "encoder.projection.0.weight": np.s_[::4, ::32],
+    "attention_refinement.attention.in_proj_weight": np.s_[::8, ::8], "attention_refinement.ffn.0.weight": np.s_[::8, ::8],
+    "decoder.lstm.weight_hh_l0": np.s_[::16, ::8], "decoder.lstm.weight_ih_l1": np.s_[::16, ::8],
+    "decoder.attention.weight": np.s_[::4, ::8], "decoder.output_projection.3.weight": np.s_[::40, ::4],
+    "decoder.embedding.weight": np.s_[::40, ::4],
+}

@@ -278,6 +278,54 @@ def golden_kd_step():
         d_projw=(pj["feature_projection.0.weight"].detach() - pj_before)[::16, ::16])
 
 
+# ------------------------------------------------------------------ (7b) the same step at a larger batch, fp32 AND fp64
+from oracle.make_golden_keys import B16_KEYS  # noqa: E402
+
+
+def golden_kd_step_b16(B=16):
+    """Forward + backward of the cfg3 KD step through the reference's own modules at B = 16, once in float32 (the
+    reference's arithmetic) and once in float64 (the yardstick): the GPU test holds the HIP gradients to
+    err(hip, fp64) <= 1.2 x err(reference fp32, fp64) per tensor group."""
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.manual_seed(0)
+        torch.set_default_dtype(dt)      # the reference creates its LSTM state with a bare torch.zeros (student_model.py:167-171)
+        t = build_teacher().to(dt)
+        s = ref_student.CaptioningStudent(V, 256, 512, 2, dropout=0.3, use_attention_refinement=True)
+        apply_seeded_init(s, seed=0)
+        zero_dropout(s)
+        s.to(dt).train()
+        projectors = ref_kd.create_feature_projectors(t, s)
+        apply_seeded_init(projectors["encoder"], seed=2)
+        zero_dropout(projectors["encoder"])
+        projectors["encoder"].to(dt)
+        images, caps = synthetic_batch(B, V, T1, seed=1234)
+        cin, ctg = caps[:-1], caps[1:]
+        # TeacherWrapper casts to .float() (distillation_utils.py:273): for the fp64 yardstick call the teacher's own
+        # forward pieces instead (same computation, no cast)
+        with torch.no_grad():
+            t_logits = t(images.to(dt), cin)
+            t_feats = t.encoder_projection(t.encoder.forward_features(images.to(dt)))
+        L = ref_kd.DistillationLoss(alpha=0.7, beta=0.2, gamma=0.1, temperature=4.0, vocab_size=V)
+        logits, enc, hids, attw = s(images.to(dt), cin)
+        s_out = {"logits": logits, "encoder_features": enc, "hidden_states": hids}
+        t_out = {"logits": t_logits, "encoder_features": projectors["encoder"](t_feats), "hidden_states": None}
+        loss, parts = L(s_out, t_out, ctg)
+        loss.backward()
+        sd = dict(s.named_parameters())
+        out[f"loss_{tag}"] = loss.detach()
+        out[f"kd_{tag}"] = np.float64(parts["token_kd_loss"])
+        out[f"feat_{tag}"] = np.float64(parts["feature_kd_loss"])
+        out[f"logits_{tag}"] = logits.detach()[::2, :, ::25]
+        out[f"enc_{tag}"] = enc.detach()[:, ::4, ::4]
+        for k, sl in B16_KEYS.items():
+            out[f"g_{tag}:{k}"] = sd[k].grad[sl]
+        print(f"  {tag}: loss {float(loss):.6f}")
+    torch.set_default_dtype(torch.float32)
+    out["keys"] = np.array(sorted(B16_KEYS))
+    npz(f"kd_step_cfg3_B{B}.npz", **out)
+
+
 # ------------------------------------------------------------------ (9) teacher beam search (SURVEY §8(f) N1)
 def golden_beam():
     t = build_teacher()
@@ -361,9 +409,9 @@ def golden_param_counts():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "beam", "optloss"]
+    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "kd_step_b16", "beam", "optloss"]
     fns = {"counts": golden_param_counts, "losses": golden_losses, "projector": golden_projector,
            "refinement": golden_refinement, "decoders": golden_decoders, "cfg1": golden_cfg1,
-           "teacher": golden_teacher, "kd_step": golden_kd_step, "beam": golden_beam, "optloss": golden_optloss}
+           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "beam": golden_beam, "optloss": golden_optloss}
     for w in which:
         fns[w]()

@@ -20,7 +20,7 @@ def test_header_symbols_are_exported():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(L, name), f"libick.so does not export {name} declared in include/ick.h"
-    assert _lib.lib().ick_abi_version() == 2
+    assert _lib.lib().ick_abi_version() == _lib.ABI_VERSION == 3
     # every extern "C" entry of the sources is declared in the header (no undeclared ABI)
     import glob
     import re
@@ -195,6 +195,7 @@ def test_checkpoint_has_the_reference_layout(tmp_path):
         pr = D.create_feature_projectors(t, s)
     tr = KDTrainer(s, t, pr, vocab_size=60, batch_size=2, t_plus_1=8, use_graph=False)
     tr.step_count = 3
+    tr.applied_steps_dev.fill_(3)
     tr.flat.exp_avg.uniform_(-1, 1)
     tr.flat.exp_avg_sq.uniform_(0, 1)
     ck = tr.checkpoint(epoch=4, val_loss=1.25, val_bleu=0.5)

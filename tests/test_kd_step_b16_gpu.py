@@ -1,0 +1,74 @@
+"""Gradient parity of the cfg3 KD step at a well-conditioned batch (B = 16) with an fp64 yardstick.
+
+tests/golden/kd_step_cfg3_B16.npz holds slices of the gradients the REFERENCE's own modules produce for this step in
+float32 (its arithmetic) and in float64 (oracle/make_goldens.py::golden_kd_step_b16; reference path
+/root/reference/src/train_student_kd.py:262-288 with AMP off, dropout p = 0).  The problem is ill-conditioned through
+the train-mode ResNet trunk with random-init weights: the reference's fp32 gradients are themselves ~1e-2 (relative L2)
+away from the fp64 evaluation in layer3/layer4.  The bar for the HIP path is therefore stated against that yardstick:
+
+    err(hip, fp64) <= 1.2 x err(reference fp32, fp64)      per tensor group (mean over the group's tensors)
+    err(hip, fp64) <= 2.5e-2 trunk, 2e-3 elsewhere         absolute relative-L2 ceilings
+    logits / features / loss terms <= 1e-3                 (north_star)
+
+Round 1 failed the first line by 1.5-3x: one MFMA accumulator summed all of K as a single fp32 chain (K up to 4608);
+the kernels now fold the chain every 128 k into a master sum (IckGemm.kchunk), like the K-blocking of a CPU GEMM."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, t
+
+pytestmark = pytest.mark.gpu
+
+GROUPS = {"layer3": "encoder.resnet.6.", "layer4": "encoder.resnet.7.", "projection": "encoder.projection.",
+          "refinement": "attention_refinement.", "decoder": "decoder."}
+CEIL = {"layer3": 2.5e-2, "layer4": 2.5e-2, "projection": 2e-3, "refinement": 2e-3, "decoder": 2e-3}
+
+
+def l2(a, b):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_kd_step_b16_gradients_vs_fp64_yardstick():
+    from imagecaptioner_amd.distillation_utils import DistillationLoss, TeacherWrapper
+    from imagecaptioner_amd.train_student_kd import build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    from oracle.make_golden_keys import B16_KEYS
+    g = load_golden("kd_step_cfg3_B16.npz")
+    B = 16
+    student, teacher, projectors = build_kd_models(device="cuda")
+    for m in list(student.modules()) + list(projectors["encoder"].modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    student.attention_refinement.attention.dropout = 0.0
+    student.decoder.lstm.dropout = 0.0
+    student.train()
+    images, caps = synthetic_batch(B, 5000, 16, seed=1234)
+    images, caps = images.cuda(), caps.cuda()
+    cin, ctg = caps[:-1], caps[1:]
+    t_out = TeacherWrapper(teacher)(images, cin)
+    logits, enc, hids, _ = student(images, cin)
+    t_out["encoder_features"] = projectors["encoder"](t_out["encoder_features"])
+    loss, parts = DistillationLoss(0.7, 0.2, 0.1, 4.0, 5000)({"logits": logits, "encoder_features": enc, "hidden_states": hids},
+                                                             t_out, ctg)
+    loss.backward()
+    # forward quantities against the reference's fp32 values (north_star: 1e-3)
+    lg = logits[::2, :, ::25].detach().cpu()
+    assert (lg - t(g["logits_f32"])).abs().max().item() < 1e-3
+    assert (enc[:, ::4, ::4].detach().cpu() - t(g["enc_f32"])).abs().max().item() < 1e-3
+    assert abs(float(loss) - float(g["loss_f32"])) < 1e-3 * abs(float(g["loss_f32"]))
+    assert abs(parts["token_kd_loss"] - float(g["kd_f32"])) < 1e-3 * abs(float(g["kd_f32"]))
+    assert abs(parts["feature_kd_loss"] - float(g["feat_f32"])) < 1e-3 * max(1.0, abs(float(g["feat_f32"])))
+    sd = dict(student.named_parameters())
+    rows = []
+    for k, sl in B16_KEYS.items():
+        hip = sd[k].grad.detach().cpu()[sl]
+        rows.append((k, l2(hip, g[f"g_f64:{k}"]), l2(g[f"g_f32:{k}"], g[f"g_f64:{k}"])))
+    report = "\n".join(f"{k:55s} hip {a:.2e}  ref32 {c:.2e}  ratio {a / max(c, 1e-30):.2f}" for k, a, c in rows)
+    print(report)
+    for name, pre in GROUPS.items():
+        sel = [(a, c) for k, a, c in rows if k.startswith(pre)]
+        hip_m, ref_m = float(np.mean([a for a, _ in sel])), float(np.mean([c for _, c in sel]))
+        assert hip_m <= 1.2 * ref_m, f"{name}: hip {hip_m:.3e} vs reference-fp32 {ref_m:.3e} (x{hip_m / ref_m:.2f})\n{report}"
+        assert hip_m <= CEIL[name], f"{name}: {hip_m:.3e} > {CEIL[name]}\n{report}"

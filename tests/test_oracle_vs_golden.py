@@ -201,6 +201,35 @@ def test_kd_step_train_mode():
     close(ssd["encoder.resnet.7.2.bn3.running_var"], g["l4_bn3_running_var"], 1e-4, "l4 bn3 running_var")
 
 
+def test_kd_step_b16_fp32_and_fp64_yardstick():
+    """The B = 16 fixture: the restatement reproduces the reference's fp32 gradients (same torch primitives) and, run in
+    float64, its fp64 gradients; the fixture's own fp32-vs-fp64 distance is the yardstick of tests/test_kd_step_b16_gpu.py."""
+    from oracle.make_golden_keys import B16_KEYS
+    g = load_golden("kd_step_cfg3_B16.npz")
+    trainable = lambda k: not any(k.startswith(f"encoder.resnet.{i}.") for i in (0, 1, 4, 5)) and "running_" not in k
+    l2 = lambda a, b: ((torch.as_tensor(a).double() - torch.as_tensor(b).double()).norm() / torch.as_tensor(b).double().norm()).item()
+    for tag, dt, tol in (("f32", torch.float32, 2e-2), ("f64", torch.float64, 1e-9)):
+        torch.set_default_dtype(dt)
+        try:
+            cast = lambda sd: {k: (v.to(dt) if v.dtype.is_floating_point else v) for k, v in sd.items()}
+            ssd = leafs(cast(seeded_state_dict(R.student_state_shapes(5000, 256, 512, 2, True), seed=0)), trainable)
+            tsd = cast(seeded_state_dict(R.teacher_state_shapes(5000, 512, 4), seed=1))
+            psd = leafs(cast(seeded_state_dict(R.projector_state_shapes(512, 256), seed=2)))
+            images, caps = synthetic_batch(16, 5000, 16, seed=1234)
+            loss, parts, logits = R.kd_forward_backward(ssd, tsd, psd, images.to(dt), caps, hidden=512, layers=2, refine=True,
+                                                        t_heads=8, t_layers=4)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        assert abs(float(loss) - float(g[f"loss_{tag}"])) < 1e-5 * abs(float(g[f"loss_{tag}"]))
+        close(logits[::2, :, ::25].float(), t(g[f"logits_{tag}"]).float(), 1e-4, f"logits {tag}")
+        for k, sl in B16_KEYS.items():
+            # fp32: two fp32 runs of an ill-conditioned problem differ by their rounding noise only if the op ORDER differs;
+            # the restatement calls the same primitives, so it lands within the problem's fp32 noise (<= 2e-2 rel-L2)
+            assert l2(ssd[k].grad[sl], g[f"g_{tag}:{k}"]) < tol, (tag, k, l2(ssd[k].grad[sl], g[f"g_{tag}:{k}"]))
+    worst = max(l2(g[f"g_f32:{k}"], g[f"g_f64:{k}"]) for k in B16_KEYS if k.startswith("encoder.resnet."))
+    assert 1e-3 < worst < 5e-2      # the yardstick itself: reference fp32 vs fp64 through the train-mode trunk
+
+
 @pytest.mark.parametrize("epoch", [0, 1, 3, 7])
 def test_optimized_distillation_loss(golden, epoch):
     """N4: oracle restatement of the reference's OptimizedDistillationLoss vs goldens captured from the reference class."""
