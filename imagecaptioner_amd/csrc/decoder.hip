@@ -18,6 +18,11 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
 // one 1024-thread workgroup (16 waves) per image b; L positions (49), E features (<= 1024).
@@ -38,11 +43,13 @@ __global__ __launch_bounds__(ANT) void attn_step_fwd_kernel(const float* __restr
   const float* F = feats + (long)b * L * E;
   for (int e = tid; e < E; e += ANT) hrow[e] = hW[(long)b * E + e];
   __syncthreads();
+  // A score is a sum of E tanh values (|score| up to ~E) feeding a softmax: its ABSOLUTE rounding error is what the
+  // attention weights see, so the E terms are summed in fp64 (4 per lane + a shuffle tree: free) and rounded once.
   for (int j = wave; j < L; j += ANT / 64) {
-    float s = 0.f;
-    for (int e = lane; e < E; e += 64) s += tanhf(U[(long)j * E + e] + hrow[e]);
-    s = wave_sum(s);
-    if (lane == 0) sc[j] = s;
+    double s = 0.0;
+    for (int e = lane; e < E; e += 64) s += (double)tanhf(U[(long)j * E + e] + hrow[e]);
+    s = wave_sum_d(s);
+    if (lane == 0) sc[j] = (float)s;
   }
   __syncthreads();
   if (wave == 0) {  // softmax over the L positions
@@ -92,18 +99,21 @@ __global__ __launch_bounds__(ANT) void attn_step_bwd_kernel(const float* __restr
   for (int e = tid; e < E; e += ANT) dc[e] = dctx[(long)b * E + e];
   for (int j = tid; j < L; j += ANT) wl[j] = w[(long)b * L + j];
   __syncthreads();
-  for (int j = wave; j < L; j += ANT / 64) {  // dw_j = <dctx, f_j>
-    float s = 0.f;
-    for (int e = lane; e < E; e += 64) s += dc[e] * feats[base + (long)j * E + e];
-    s = wave_sum(s);
-    if (lane == 0) ds[j] = s;
+  // softmax adjoint ds_j = w_j (dw_j - sum_i w_i dw_i), dw_j = <dctx, f_j>: with a peaky softmax the bracket cancels
+  // to a small fraction of dw_j, so dw_j and the weighted mean are formed in fp64 (49 x E products per image: free)
+  double* dwd = reinterpret_cast<double*>(part);      // [Lp] fp64 scratch (part is not live yet; 8-byte aligned: see launcher)
+  for (int j = wave; j < L; j += ANT / 64) {
+    double s = 0.0;
+    for (int e = lane; e < E; e += 64) s = fma((double)dc[e], (double)feats[base + (long)j * E + e], s);
+    s = wave_sum_d(s);
+    if (lane == 0) dwd[j] = s;
   }
   __syncthreads();
-  if (wave == 0) {  // softmax adjoint: ds_j = w_j (dw_j - sum_i w_i dw_i)
-    float d = 0.f;
-    for (int j = lane; j < L; j += 64) d += wl[j] * ds[j];
-    d = wave_sum(d);
-    for (int j = lane; j < L; j += 64) ds[j] = wl[j] * (ds[j] - d);
+  if (wave == 0) {
+    double d = 0.0;
+    for (int j = lane; j < L; j += 64) d = fma((double)wl[j], dwd[j], d);
+    d = wave_sum_d(d);
+    for (int j = lane; j < L; j += 64) ds[j] = (float)((double)wl[j] * (dwd[j] - d));
   }
   __syncthreads();
   const int ng = ANT / E;
@@ -307,7 +317,8 @@ int ick_attn_step_bwd(const float* dctx, const float* w, const float* Uf, const 
                       float* dfeats, float* dhW, int B, int L, int E, void* stream) {
   ICK_REQUIRE(dctx && w && Uf && hW && feats && dUf && dfeats && dhW && B > 0 && L > 0 && E > 0,
               "ick_attn_step_bwd: bad arguments");
-  ICK_REQUIRE(E <= ANT, "ick_attn_step_bwd: E <= 1024");
+  ICK_REQUIRE(E <= ANT && E % 2 == 0, "ick_attn_step_bwd: E <= 1024 and even");
+  ICK_REQUIRE(2 * ((L + 3) & ~3) <= (ANT / E) * E, "ick_attn_step_bwd: L too large for the fp64 scratch (L=%d, E=%d)", L, E);
   const size_t sh = (2 * ((L + 3) & ~3) + E + (size_t)(ANT / E) * E) * sizeof(float);
   ICK_LAUNCH(attn_step_bwd_kernel, dim3(B), dim3(ANT), sh, ST, dctx, w, Uf, hW, feats, dUf, dfeats, dhW, L, E);
   return ick::launch_status("attn_step_bwd");

@@ -276,10 +276,12 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   // Chunked accumulation: one MFMA accumulator is a strictly sequential fp32 chain over k, whose rounding error grows
   // with the chain length (measured: a K = 4608 chain is 4x further from fp64 than a K-blocked CPU GEMM, and that excess
-  // shows up 1.5-3x in every gradient behind the ResNet trunk).  Every p.chunk_tiles k-tiles (128 k by default; CPU
+  // shows up 1.5-3x in every gradient behind the ResNet trunk).  Every p.chunk_tiles k-tiles (64 k by default; CPU
   // GEMMs block K at ~256) the chain is folded into a master sum and restarted from zero.  Measured on the KD step
-  // (tools/diag_grads.py, profiles/r02_diag_grads_B{2,8}.log): gradient error vs fp64 relative to torch's CPU fp32 falls
-  // from 4.3-4.5x (refinement / decoder, B = 8) to 0.98x, trunk 1.10x -> 0.92x.
+  // (tools/diag_grads.py, profiles/r02_diag_grads_B{2,8}.log, chunk 128): gradient error vs fp64 relative to torch's
+  // CPU fp32 falls from 4.3-4.5x (refinement / decoder, B = 8) to 0.98x, trunk 1.10x -> 0.92x; an isolated K = 2304
+  // data gradient goes from 1.8e-6 to 2.6e-7 of scale.  Cost: none measurable (29.83 vs 29.81 ms/step at chunk 64 / 128,
+  // 194.3 vs 195.1 us for the ViT fc1 GEMM with / without folding): the fold's VALU adds hide under other waves' MFMAs.
   f32x16 tot[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)

@@ -82,7 +82,7 @@ inline int prepare(const IckGemm* d, int bk, P& p, int& nz, const char* who) {
   nz = bo * p.batch_inner;
   {
     static const int env_chunk = [] { const char* e = getenv("ICK_KCHUNK"); return e ? atoi(e) : 0; }();   // A/B runs
-    const int kc = d->kchunk != 0 ? d->kchunk : (env_chunk != 0 ? env_chunk : 128);
+    const int kc = d->kchunk != 0 ? d->kchunk : (env_chunk != 0 ? env_chunk : 64);
     p.chunk_tiles = kc > 0 ? (kc + bk - 1) / bk : 0;
   }
   ICK_REQUIRE((d->stat_sum == nullptr) == (d->stat_sq == nullptr), "%s: stat_sum and stat_sq go together", who);

@@ -225,9 +225,10 @@ __global__ void bn_train_apply_kernel(const float* __restrict__ x, const double*
 
 // BN backward pass 1: per channel sum(g) and sum(g * xhat), g = dy * (y > 0) when y != NULL.
 // Block = 256 threads as (ROWS x C4 lanes); each thread owns 4 channels, strides over rows; LDS combine, atomics out.
-// Accumulation: fp32 inside one trip of 4 rows, then fp64 per thread, fp64 in the LDS combine and fp64 atomics — the
-// reference's CPU batch_norm backward reduces in double (at::acc_type<float, /*is_cuda=*/false>), and these two sums are
-// differences of large terms (sum g is ~0 behind a mean-subtracting layer).
+// Arithmetic: the reference's CPU batch_norm backward reduces in double (at::acc_type<float, /*is_cuda=*/false>):
+// sum += dy, dotp += (x - mean) * dy with every term converted first.  Same here — products and sums in fp64 per
+// thread, fp64 LDS combine, fp64 atomics; invstd is applied once to the finished dot product.  (Both sums are
+// differences of large terms behind a mean-subtracting layer; the kernel is HBM-bound, the fp64 VALU work is free.)
 struct d4 { double x, y, z, w; };
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                      const float* __restrict__ x, const float* __restrict__ mean,
@@ -239,8 +240,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
   const int tc = threadIdx.x % lanes, tr = threadIdx.x / lanes;
   __shared__ d4 sh_g[NT], sh_x[NT];
   for (int c4 = blockIdx.x * lanes + tc; c4 < C4; c4 += gridDim.x * lanes) {
-    const float4 mu = reinterpret_cast<const float4*>(mean)[c4];
-    const float4 iv = reinterpret_cast<const float4*>(inv)[c4];
+    const float4 muf = reinterpret_cast<const float4*>(mean)[c4];
+    const d4 mu = {muf.x, muf.y, muf.z, muf.w};
     d4 dg = {0, 0, 0, 0}, dx = {0, 0, 0, 0};
     if (tr < rows) {
       // 4 rows per trip: 12 independent 16-byte loads in flight per thread (one row per trip left the kernel
@@ -256,19 +257,16 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
           xv[u] = reinterpret_cast<const float4*>(x)[o];
           if (y) yy[u] = reinterpret_cast<const float4*>(y)[o];
         }
-        float4 ag = make_float4(0, 0, 0, 0), ax = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (y) {
             g[u].x = yy[u].x > 0.f ? g[u].x : 0.f; g[u].y = yy[u].y > 0.f ? g[u].y : 0.f;
             g[u].z = yy[u].z > 0.f ? g[u].z : 0.f; g[u].w = yy[u].w > 0.f ? g[u].w : 0.f;
           }
-          ag.x += g[u].x; ag.y += g[u].y; ag.z += g[u].z; ag.w += g[u].w;
-          ax.x += g[u].x * (xv[u].x - mu.x) * iv.x; ax.y += g[u].y * (xv[u].y - mu.y) * iv.y;
-          ax.z += g[u].z * (xv[u].z - mu.z) * iv.z; ax.w += g[u].w * (xv[u].w - mu.w) * iv.w;
+          dg.x += g[u].x; dg.y += g[u].y; dg.z += g[u].z; dg.w += g[u].w;
+          dx.x = fma((double)g[u].x, (double)xv[u].x - mu.x, dx.x); dx.y = fma((double)g[u].y, (double)xv[u].y - mu.y, dx.y);
+          dx.z = fma((double)g[u].z, (double)xv[u].z - mu.z, dx.z); dx.w = fma((double)g[u].w, (double)xv[u].w - mu.w, dx.w);
         }
-        dg.x += ag.x; dg.y += ag.y; dg.z += ag.z; dg.w += ag.w;
-        dx.x += ax.x; dx.y += ax.y; dx.z += ax.z; dx.w += ax.w;
       }
       for (; m < M; m += step) {
         const long o = m * C4 + c4;
@@ -280,8 +278,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
         }
         const float4 xv = reinterpret_cast<const float4*>(x)[o];
         dg.x += g.x; dg.y += g.y; dg.z += g.z; dg.w += g.w;
-        dx.x += g.x * (xv.x - mu.x) * iv.x; dx.y += g.y * (xv.y - mu.y) * iv.y;
-        dx.z += g.z * (xv.z - mu.z) * iv.z; dx.w += g.w * (xv.w - mu.w) * iv.w;
+        dx.x = fma((double)g.x, (double)xv.x - mu.x, dx.x); dx.y = fma((double)g.y, (double)xv.y - mu.y, dx.y);
+        dx.z = fma((double)g.z, (double)xv.z - mu.z, dx.z); dx.w = fma((double)g.w, (double)xv.w - mu.w, dx.w);
       }
     }
     sh_g[threadIdx.x] = dg; sh_x[threadIdx.x] = dx;
@@ -292,9 +290,10 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
         dg.x += a.x; dg.y += a.y; dg.z += a.z; dg.w += a.w;
         dx.x += b.x; dx.y += b.y; dx.z += b.z; dx.w += b.w;
       }
+      const float4 iv = reinterpret_cast<const float4*>(inv)[c4];
       double* sg = sum_g + c4 * 4; double* sx = sum_gx + c4 * 4;
       atomicAdd(sg + 0, dg.x); atomicAdd(sg + 1, dg.y); atomicAdd(sg + 2, dg.z); atomicAdd(sg + 3, dg.w);
-      atomicAdd(sx + 0, dx.x); atomicAdd(sx + 1, dx.y); atomicAdd(sx + 2, dx.z); atomicAdd(sx + 3, dx.w);
+      atomicAdd(sx + 0, dx.x * iv.x); atomicAdd(sx + 1, dx.y * iv.y); atomicAdd(sx + 2, dx.z * iv.z); atomicAdd(sx + 3, dx.w * iv.w);
     }
     __syncthreads();
   }

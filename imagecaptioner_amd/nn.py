@@ -414,8 +414,8 @@ class ResNetTrunkFn(Function):
         y = ops.maxpool3x3s2(y)
         first = next((i for i, b in enumerate(blocks) if _block_trainable(b)), len(blocks))
         want_bwd = any(ctx.needs_input_grad) and first < len(blocks)   # (forward itself always runs in no-grad mode)
-        if want_bwd and not train:
-            raise NotImplementedError("backward through eval-mode BatchNorm is not needed by the KD step")
+        ctx.eval_mode_graph = want_bwd and not train     # eval forward under autograd (validation loops): fine until .backward()
+        want_bwd = want_bwd and train
         recs = []
         for i, blk in enumerate(blocks):
             y, rec = bottleneck_forward(blk, y, train, arena, counters)
@@ -430,6 +430,8 @@ class ResNetTrunkFn(Function):
     @staticmethod
     def backward(ctx, dy):
         blocks, first, recs = ctx.blocks, ctx.first, ctx.recs
+        if ctx.eval_mode_graph:
+            raise NotImplementedError("backward through eval-mode BatchNorm is not needed by the KD step")
         if not recs:
             return (None,) * len(ctx.needs_input_grad)
         d = _c(dy).view(recs[-1]["out"].shape)

@@ -45,7 +45,7 @@ def zeros(*shape, device=None) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------- raw GEMM
 _FORCE_TILE = [0]       # tools/profile_step_gemms.py sweeps tile shapes through this
-_KCHUNK = [0]           # diagnostics: IckGemm.kchunk of every descriptor (0 = library default 128, -1 = one chain over K)
+_KCHUNK = [0]           # diagnostics: IckGemm.kchunk of every descriptor (0 = library default 64, -1 = one chain over K)
 _TILE_OR = [0]          # diagnostics: bits OR-ed into every descriptor's tile field (512 = direct epilogue)
 
 

@@ -73,7 +73,7 @@ typedef struct IckGemm {
   int32_t stat_copies;                          /* <= 1: one accumulator row; R > 1: stat_sum/stat_sq are [R][stat_stride] and the row-tile t of the grid adds into copy t % R (spreads the fp64 atomics of large-M convolutions over R x as many cache lines; consumers sum the copies) */
   int64_t stat_stride;                          /* elements between two copies (>= N) */
   const float* col_scale;                       /* [N] or NULL: C = act(col_scale[n] * alpha*sum + bias[n] ...) — eval-mode BatchNorm folded into the conv epilogue (scale = gamma/sqrt(var+eps), bias = shift); needs N %% 4, ldc %% 4, no split-K */
-  int32_t kchunk;                               /* fp32 kernels: k elements one MFMA accumulator chain sums before it is folded into a master accumulator (bounds the rounding error of long-K products the way a K-blocked CPU GEMM does); 0 = library default (128), < 0 = one chain over all of K */
+  int32_t kchunk;                               /* fp32 kernels: k elements one MFMA accumulator chain sums before it is folded into a master accumulator (bounds the rounding error of long-K products the way a K-blocked CPU GEMM does); 0 = library default (64), < 0 = one chain over all of K */
 } IckGemm;
 
 int ick_gemm_f32(const IckGemm* desc, void* stream);
