@@ -422,6 +422,7 @@ int launch(const P& p0, int nz, hipStream_t st) {
 // the grid costs max-per-CU work.  tile: 0 = model, 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128.
 template <int OP>
 int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
+  tile &= 15;    // the +16 (three LDS buffers) / +32 (M-split) variants exist in the LDS-DMA kernel only
   if (tile == 0) {
     static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
     static const double eff[4] = {1.00, 0.80, 0.90, 0.90};   // relative MFMA efficiency of the tile shape

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
   const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;   // XCD-aware tile order (igemm_f32.hip)
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_base + tile_m * BM, n0 = tile_n * BN;   // m_base: first row of this launch (M-split dispatch)
 
   int z = blockIdx.z, split = 0;
   if (p.splitk > 1) { split = z; z = 0; }
@@ -475,42 +475,85 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
   else epilogue(std::false_type{});
 }
 
+// rows [m_begin, m_end) of the problem (m_end <= 0: all of M).  A launch over a row range is what the M-split dispatch
+// uses: bounds are checked against p.M = m_end, addresses are formed from the global row index.
 template <int OP, int BM, int BN, int NBUF>
-int launch(const P& p0, int nz, hipStream_t st) {
+int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) {
   P p = p0;
+  if (m_end <= 0 || m_end > p.M) m_end = p.M;
+  p.m_base = m_begin;
+  p.M = m_end;
   p.tiles_n = (p.N + BN - 1) / BN;
   // 16-byte stores need every row start of C (and of the residual) 16-byte aligned
   p.ep_vec = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.sCo | p.sCi) % 4 == 0 && ick::aligned16(p.C) &&
              (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual))) && !g_no_vec_epilogue && !p.no_ep_vec;
   if ((p.col_scale || (p.act & ICK_ACT_POST_RESIDUAL)) && !(p.ep_vec && p.splitk == 1))
     return ick::fail(-1, "igemm: col_scale / ICK_ACT_POST_RESIDUAL need 16-byte aligned C rows (N %% 4, ldc %% 4) and no split-K");
-  dim3 grid(p.tiles_n * ((p.M + BM - 1) / BM), 1, nz);
+  dim3 grid(p.tiles_n * ((p.M - m_begin + BM - 1) / BM), 1, nz);
   ICK_LAUNCH((igemm_f32_glds_kernel<OP, BM, BN, NBUF>), grid, dim3(NT), 0, st, p);
   return ick::launch_status("igemm_f32_glds");
 }
 
+constexpr int kCUs = 256;            // MI355X
+constexpr int kBodySlots = 2 * kCUs; // 128x128 workgroups resident at once (64 KiB of LDS each: two per CU)
+
+template <int OP>
+int launch_tile(const P& p, int nz, hipStream_t st, int tile, int m_begin = 0, int m_end = 0) {
+  switch (tile) {           // +16: three LDS buffers (two tiles of prefetch) instead of two
+    case 2: return launch<OP, 64, 64, 2>(p, nz, st, m_begin, m_end);
+    case 3: return launch<OP, 128, 64, 2>(p, nz, st, m_begin, m_end);
+    case 4: return launch<OP, 64, 128, 2>(p, nz, st, m_begin, m_end);
+    case 18: return launch<OP, 64, 64, 3>(p, nz, st, m_begin, m_end);
+    case 19: return launch<OP, 128, 64, 3>(p, nz, st, m_begin, m_end);
+    case 20: return launch<OP, 64, 128, 3>(p, nz, st, m_begin, m_end);
+    default: return launch<OP, 128, 128, 2>(p, nz, st, m_begin, m_end);
+  }
+}
+
+// M-split (IckGemm.tile +32): the 128x128 tile is the family's most efficient at long K (half the operand stream per FLOP
+// of the 64x64 one: 119-127 TF against ~80 at 4096^3) but a grid of T such workgroups runs in ceil(T / 512) rounds, and
+// the step's shapes leave the last round mostly empty (ViT: M = 12608 -> 2.32 rounds).  So: the rows that fill WHOLE
+// rounds go to the 128x128 kernel, the remaining rows to a second launch with a small tile whose own partial round is
+// short.  Measured (profiles/r02b_step_gemm_shapes_tile_sweep.log): a wash on the step's short-K shapes — the ViT fc1
+// GEMM takes 177 us split vs 175 (128x128 alone) vs 166-169 (64-row tiles): with K = 384 a 128x128 workgroup spends as
+// long in its prologue + GELU epilogue as two of its twelve k-tiles, and only two of them share a CU — it wins 2-3 % on
+// the K >= 512 Linear shapes (fc2, teacher decoder).  Kept as a tuned-table option, not chosen by the cost model.
+// Returns the first row of the tail (0: no full round exists -> everything is tail; M: no tail).
+inline int msplit_row(const P& p, int nz) {
+  if (nz != 1) return 0;
+  const long tiles_n = (p.N + 127) / 128, tiles_m = (p.M + 127) / 128;
+  const long rounds = tiles_m * tiles_n / kBodySlots;
+  long rows = rounds * kBodySlots / tiles_n;                 // tile rows of the body
+  if (rows >= tiles_m) return p.M;
+  return (int)(rows * 128);
+}
+
 template <int OP>
 int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
+  static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
+  static const double eff[4] = {1.00, 0.85, 0.93, 0.93};   // relative efficiency of the tile shape
+  bool split = (tile & 32) != 0;
+  tile &= 31;
   if (tile == 0) {
-    static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
-    static const double eff[4] = {1.00, 0.85, 0.93, 0.93};   // relative efficiency of the tile shape
     double best = 1e300;
+    auto cost_of = [&](int t, long rows) {                   // busiest CU's share of tile area / efficiency
+      const long blocks = ((rows + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * nz;
+      return (double)((blocks + kCUs - 1) / kCUs) * bm[t] * bn[t] / eff[t];
+    };
     for (int t = 0; t < 4; ++t) {
-      const long blocks = (long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * nz;
-      const long per_cu = (blocks + 255) / 256;
-      const double cost = (double)per_cu * bm[t] * bn[t] / eff[t];
+      const double cost = cost_of(t, p.M);
       if (cost < best * 0.999) { best = cost; tile = t + 1; }
     }
   }
-  switch (tile) {           // +16: three LDS buffers (two tiles of prefetch) instead of two
-    case 2: return launch<OP, 64, 64, 2>(p, nz, st);
-    case 3: return launch<OP, 128, 64, 2>(p, nz, st);
-    case 4: return launch<OP, 64, 128, 2>(p, nz, st);
-    case 18: return launch<OP, 64, 64, 3>(p, nz, st);
-    case 19: return launch<OP, 128, 64, 3>(p, nz, st);
-    case 20: return launch<OP, 64, 128, 3>(p, nz, st);
-    default: return launch<OP, 128, 128, 2>(p, nz, st);
+  if (split && OP != ICK_OP_CONV_DGRAD_S2) {
+    const int ms = msplit_row(p, nz);
+    if (ms >= p.M) return launch<OP, 128, 128, 2>(p, nz, st);
+    if (ms > 0) {
+      if (int rc = launch<OP, 128, 128, 2>(p, nz, st, 0, ms)) return rc;
+      return launch_tile<OP>(p, nz, st, tile, ms, p.M);
+    }
   }
+  return launch_tile<OP>(p, nz, st, tile);
 }
 
 }  // namespace

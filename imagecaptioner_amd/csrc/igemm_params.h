@@ -19,6 +19,7 @@ struct P {  // kernel parameters (by value)
   int stat_copies; long stat_stride;
   const float* col_scale;
   int no_ep_vec;   // IckGemm.tile bit 9: force the direct (dword) epilogue (A/B and diagnostics)
+  int m_base;        // first row of this launch (M-split dispatch; 0 for a whole-problem launch)
   int chunk_tiles;   // fold the MFMA accumulators into the master sum every chunk_tiles k-tiles (0 = never)
   int ep_vec;   // LDS-staged 16-byte epilogue allowed (set by the launcher from the alignment of C / residual)
 };

@@ -435,11 +435,44 @@ class ResNetTrunkFn(Function):
         if not recs:
             return (None,) * len(ctx.needs_input_grad)
         d = _c(dy).view(recs[-1]["out"].shape)
-        sums_arena = _Arena(2 * _bn_channels(blocks[first:]), torch.float64, d.device)
-        for i in range(len(blocks) - 1, first - 1, -1):
-            d = bottleneck_backward(blocks[i], recs[i - first], d, i > first, sums_arena)
-            recs[i - first] = None                                   # free this block's activations
+        state = dict(blocks=blocks, first=first, recs=recs, d=d, next=len(blocks) - 1,
+                     sums=_Arena(2 * _bn_channels(blocks[first:]), torch.float64, d.device))
+        if _TRUNK_DEFER["on"]:
+            # data-parallel step: the trainer runs the trunk's backward itself, stage by stage, so that the gradient
+            # buckets of everything ABOVE the trunk are already on the wire while layer4 / layer3 are still computing
+            _TRUNK_DEFER["pending"] = state
+        else:
+            trunk_backward_stage(state, first)
         return (None,) * len(ctx.needs_input_grad)
+
+
+_TRUNK_DEFER = {"on": False, "pending": None}
+
+
+def trunk_backward_stage(state: dict, stop: int) -> None:
+    """Backward through blocks state['next'] .. stop (descending, inclusive) of the trunk; weight / BatchNorm gradients
+    accumulate into .grad, the running dL/dx is carried in the state for the next stage."""
+    blocks, first, recs = state["blocks"], state["first"], state["recs"]
+    stop = max(stop, first)
+    for i in range(state["next"], stop - 1, -1):
+        state["d"] = bottleneck_backward(blocks[i], recs[i - first], state["d"], i > first, state["sums"])
+        recs[i - first] = None                                       # free this block's activations
+    state["next"] = stop - 1
+
+
+class deferred_trunk_backward:
+    """with deferred_trunk_backward() as box: loss.backward() stops at the trunk boundary; box.state then drives
+    trunk_backward_stage (KDTrainer's bucketed data-parallel step)."""
+
+    def __enter__(self):
+        _TRUNK_DEFER["on"], _TRUNK_DEFER["pending"] = True, None
+        self.state = None
+        return self
+
+    def __exit__(self, *exc):
+        self.state = _TRUNK_DEFER["pending"]
+        _TRUNK_DEFER["on"], _TRUNK_DEFER["pending"] = False, None
+        return False
 
 
 def resnet_trunk(images, resnet: nn.Sequential, train: bool):

@@ -98,7 +98,7 @@ class KDTrainer:
                  gamma=0.1, temperature=4.0, learning_rate=2e-4, weight_decay=0.01, max_norm=1.0, batches_per_epoch=1000,
                  batch_size: int = 64, t_plus_1: int = 16, use_graph: bool = True, process_group=None,
                  precision: str = "f32", teacher_precision: str = "f32", overlap_teacher: bool = True,
-                 accumulation_steps: int = 1, loss_scale=None, growth_interval: int = 2000):
+                 accumulation_steps: int = 1, loss_scale=None, growth_interval: int = 2000, bucketed: Optional[bool] = None):
         """precision: arithmetic of the student + projector contractions, forward and backward ("f32" exact, "bf16" =
         the reference's autocast regime :271-285 with fp32 master weights, "bf16x3" split-bf16); the teacher runs
         outside autocast in fp32 in the reference (:265-268) -> teacher_precision defaults to "f32"."""
@@ -163,8 +163,50 @@ class KDTrainer:
         self.use_graph = use_graph and self.device.type == "cuda"
         self.g_fb: Optional[torch.cuda.CUDAGraph] = None
         self.g_opt: Optional[torch.cuda.CUDAGraph] = None
+        # Data-parallel step = three stages with a gradient bucket leaving after each (dp.gradient_buckets): (0) forward +
+        # loss + backward down to the trunk boundary, (1) layer4 backward, (2) layer3 backward.  bucketed=None: on for
+        # world > 1; True forces the staged step on one rank too (tests: it must equal the single-graph step).
+        names = {id(p): k for k, p in student.named_parameters()}
+        names.update({id(p): f"projector.{k}.{n}" for k, pr in projectors.items() for n, p in pr.named_parameters()})
+        self.buckets = dp.gradient_buckets(self.flat.metas, self.flat.total, names)
+        self.bucketed = (self.world > 1) if bucketed is None else bool(bucketed)
+        if len(self.buckets) != 3:
+            self.bucketed = False
+        self.comm_stream = torch.cuda.Stream() if (self.bucketed and self.device.type == "cuda") else None
+        self.g_stage: List[Optional[torch.cuda.CUDAGraph]] = [None, None, None]
+        self._trunk_state = None
+        self._l4_first = None
 
     # ------------------------------------------------------------------ the step body
+    def _stage(self, k: int):
+        """stage k of the staged (data-parallel) step; see __init__."""
+        if k == 0:
+            with hnn.deferred_trunk_backward() as box:
+                out = self._forward_backward()
+            self._trunk_state = box.state
+            if self._l4_first is None and box.state is not None:
+                blocks = box.state["blocks"]
+                l4 = set(id(b) for b in self.student.encoder.resnet[7])
+                self._l4_first = next(i for i, b in enumerate(blocks) if id(b) in l4)
+            return out
+        if self._trunk_state is not None:
+            with ops.precision(self.precision):
+                hnn.trunk_backward_stage(self._trunk_state, self._l4_first if k == 1 else 0)
+            if k == 2:
+                self._trunk_state = None
+
+    def _reduce_bucket(self, k: int, boundary: bool):
+        """all-reduce(SUM) of bucket k on the communication stream, behind everything the launch stream has enqueued so far."""
+        if not boundary or self.world <= 1 and self.pg is None and not torch.distributed.is_initialized():
+            return
+        a, b = self.buckets[k]
+        if self.comm_stream is None:
+            dp.allreduce_gradients(self.flat.grad[a:b], self.pg)
+            return
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.comm_stream):
+            dp.allreduce_gradients(self.flat.grad[a:b], self.pg, force=True)
+
     def _forward_backward(self):
         """teacher fwd (no grad, fp32) -> student fwd -> projector -> KD loss -> backward  (reference :262-288)."""
         if self.accumulation_steps == 1:
@@ -268,8 +310,18 @@ class KDTrainer:
         torch.cuda.synchronize()
         self.g_fb = torch.cuda.CUDAGraph()
         # thread_local: under torch.distributed the RCCL watchdog thread polls events while this thread captures
-        with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
-            self._forward_backward()
+        if self.bucketed:
+            # three graphs replayed back to back share one memory pool (stage k reads what stage k-1 left behind)
+            with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
+                self._stage(0)
+            self.g_stage[0] = self.g_fb
+            for k in (1, 2):
+                self.g_stage[k] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_stage[k], pool=self.g_fb.pool(), capture_error_mode="thread_local"):
+                    self._stage(k)
+        else:
+            with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
+                self._forward_backward()
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self._optimizer()
@@ -305,14 +357,23 @@ class KDTrainer:
         boundary = (self.batch_idx + 1) % self.accumulation_steps == 0
         if boundary:
             self._update_hyper()
-        if self.use_graph:
+        if self.bucketed:
+            for k in range(3):
+                if self.use_graph:
+                    self.g_stage[k].replay()
+                else:
+                    self._stage(k)
+                self._reduce_bucket(k, boundary)
+            if self.comm_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.comm_stream)
+        elif self.use_graph:
             self.g_fb.replay()
         else:
             self._forward_backward()
         self.micro_idx += 1
         self.batch_idx += 1
         if boundary:
-            if self.world > 1:
+            if self.world > 1 and not self.bucketed:
                 dp.allreduce_gradients(self.flat.grad, self.pg)
             if self.use_graph:
                 self.g_opt.replay()

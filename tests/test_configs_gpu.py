@@ -324,3 +324,79 @@ def test_argmax_rows_edge_cases():
         want = torch.argmax(x.cpu(), dim=-1)
         assert torch.equal(got, want), (V, got, want)
         assert int(got.max()) < V and int(got.min()) >= 0
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_staged_data_parallel_step_under_an_rccl_group_equals_single_graph_step(use_graph):
+    """cfg4 rehearsal on ONE GPU: KDTrainer under an initialised `nccl` (= RCCL) process group of
+    world 1, with the staged step forced on — forward + backward to the trunk boundary / layer4 backward / layer3 backward
+    as three graphs, a bucket all-reduce on the communication stream after each — must take the same optimizer step as
+    the plain single-graph trainer.  Exercises graph capture with the RCCL watchdog alive, the deferred trunk backward,
+    the bucket boundaries and the stream joins; what it cannot show is xGMI traffic (world 1)."""
+    import torch.distributed as dist
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    images, caps = synthetic_batch(2, 5000, 16, seed=3)
+    deltas = {}
+    for staged in (False, True):
+        if staged:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                    device_id=torch.device("cuda", 0))
+        try:
+            s, t, p = build_kd_models(device="cuda")
+            _no_dropout(s, p)
+            tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=2, use_graph=use_graph, bucketed=staged)
+            assert tr.bucketed == staged and len(tr.buckets) == 3
+            before = tr.flat.param.clone()
+            tr.train_step(images.cuda(), caps.cuda())
+            tr.train_step()
+            torch.cuda.synchronize()
+            deltas[staged] = (tr.flat.param.clone() - before, tr.loss_dict()["total_loss"], tr.flat.grad.clone())
+            del tr, s, t, p
+            torch.cuda.empty_cache()
+        finally:
+            if staged:
+                dist.destroy_process_group()
+    (d0, l0, g0), (d1, l1, g1) = deltas[False], deltas[True]
+    assert abs(l0 - l1) <= 1e-4 * abs(l0)
+    assert float(d0.abs().max()) > 0
+    # same kernels in the same order: the two steps differ only by the order of fp32 atomics
+    assert float((g0 - g1).norm()) <= 2e-2 * float(g0.norm())
+    assert float((d0 - d1).abs().mean()) <= 2e-3 * float(d0.abs().mean())
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
+def test_two_rank_rccl_step_matches_serial_average():
+    """world 2 over RCCL: after one staged step both ranks hold identical parameters, and the all-reduced gradient equals
+    the sum of the two ranks' own gradients (recomputed serially on rank 0)."""
+    import subprocess
+    import sys
+    import os
+    port = _free_port()
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models\n"
+        "from imagecaptioner_amd.utils.seeded_init import synthetic_batch\n"
+        "rank = int(os.environ['RANK']); torch.cuda.set_device(rank)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', rank))\n"
+        "s, t, p = build_kd_models(device=f'cuda:{rank}')\n"
+        "tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=2, use_graph=True)\n"
+        "assert tr.bucketed and tr.world == 2\n"
+        "im, cp = synthetic_batch(2, 5000, 16, seed=3, rank=rank)\n"
+        "tr.train_step(im.cuda(), cp.cuda()); tr.train_step(); torch.cuda.synchronize()\n"
+        "chk = tr.flat.param.double().sum().reshape(1); both = [torch.zeros_like(chk) for _ in range(2)]\n"
+        "dist.all_gather(both, chk)\n"
+        "assert float((both[0] - both[1]).abs()) == 0.0, both\n"
+        "dist.destroy_process_group(); print('ranks agree')\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), "-c", code], env=env, capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+    assert r.returncode == 0 and "ranks agree" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -39,7 +39,9 @@ def _shard_grads(rank: int):
 def _flat_from(grads, shapes):
     from imagecaptioner_amd.train_student_kd import FlatParams
     params = [(k, torch.nn.Parameter(torch.zeros(shapes[k]).contiguous(memory_format=torch.channels_last)
-                                     if len(shapes[k]) == 4 else torch.zeros(shapes[k]))) for k in sorted(shapes)]
+                                     if len(shapes[k]) == 4 else torch.zeros(shapes[k])))
+              # module order of CNNEncoder.parameters(): the ResNet children first, then the projection
+              for k in sorted(shapes, key=lambda k: (not k.startswith("encoder.resnet."), k))]
     enc = [p for k, p in params if k.startswith("encoder.")]
     dec = [p for k, p in params if k.startswith("decoder.")]
     fp = FlatParams([("encoder", enc), ("decoder", dec), ("refine", []), ("projector", [])], torch.device("cpu"))
@@ -56,7 +58,18 @@ def _worker(rank, world, port, out):
     grads, shapes = _shard_grads(rank)
     fp, _ = _flat_from(grads, shapes)
     assert dp.world_size() == world
-    dp.allreduce_gradients(fp.grad)
+    # the trainer's three buckets (above-the-trunk, layer4, layer3), reduced one by one in completion order, must cover the
+    # buffer exactly once: reducing them == reducing the whole buffer
+    fp, params = _flat_from(grads, shapes)
+    names = {id(p): k for k, p in params.items()}
+    buckets = dp.gradient_buckets(fp.metas, fp.total, names)
+    assert len(buckets) == 3 and buckets[0][1] == fp.total and buckets[2][0] == 0
+    assert buckets[0][0] == buckets[1][1] and buckets[1][0] == buckets[2][1]
+    l4 = [o for p_, o, n in fp.metas if names[id(p_)].startswith("encoder.resnet.7.")]
+    l3 = [o for p_, o, n in fp.metas if names[id(p_)].startswith("encoder.resnet.6.")]
+    assert min(l4) == buckets[1][0] and max(l3) < buckets[1][0] and max(l4) < buckets[0][0]
+    for a, b in buckets:
+        dp.allreduce_gradients(fp.grad[a:b])
     if rank == 0:
         torch.save(fp.grad / world, out)
     torch.distributed.barrier()

@@ -158,3 +158,31 @@ def test_conv_stem_c4(ops):
     assert rel_err(stats[1], (ref * ref).sum((0, 2, 3))) < max(1e-4, 5 * TOL)
     mp = ops.maxpool3x3s2(y)
     assert torch.equal(mp.permute(0, 3, 1, 2).cpu(), F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 3, 2, 1))
+
+
+@pytest.mark.parametrize("tile", [34, 35, 36, 50, 0])
+def test_msplit_dispatch_linear_and_conv_vs_fp64(tile):
+    """IckGemm.tile +32: rows that fill whole rounds of the chip run on 128x128 workgroups, the remaining rows in a second
+    launch with a smaller tile (tile 0 lets the library's cost model decide).  Both launches must cover every row exactly
+    once — bias / GELU / residual, BatchNorm statistics and a ragged M included."""
+    from imagecaptioner_amd import ops as o
+    from imagecaptioner_amd._lib import ACT_GELU, OP_NT
+    M, N, K = 64 * 197, 1536, 96                      # the ViT fc1 geometry with a short K: 99 x 12 tiles = 2.32 rounds
+    x, w, b, r = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3), rnd(M, N, seed=4)
+    xd, wd, bd, rd = (t.cuda() for t in (x, w, b, r))
+    y = torch.zeros(M, N, device="cuda")
+    o.gemm_raw(OP_NT, xd.data_ptr(), wd.data_ptr(), y.data_ptr(), M, N, K, K, K, N, bias=bd.data_ptr(), act=ACT_GELU,
+               residual=rd.data_ptr(), ldr=N, tile=tile)
+    ref = F.gelu(x.double() @ w.double().T + b.double()) + r.double()
+    assert rel_err(y, ref) < 2e-5
+    # convolution + statistics: 64 x 14 x 14 pixels, 256 -> 1024 channels: 98 x 8 tiles = 1.53 rounds
+    xc, wc = rnd(64, 14, 14, 256, seed=5), rnd(1024, 1, 1, 256, seed=6, scale=0.05)
+    stats = torch.zeros(2, 1024, dtype=torch.float64, device="cuda")
+    o._FORCE_TILE[0] = tile
+    try:
+        raw = o.conv_fwd(xc.cuda(), wc.cuda(), 1, 0, stats=(stats[0], stats[1]))
+    finally:
+        o._FORCE_TILE[0] = 0
+    refc = xc.double().view(-1, 256) @ wc.double().view(1024, 256).T
+    assert rel_err(raw.view(-1, 1024), refc) < 2e-5
+    assert rel_err(stats[0], refc.sum(0)) < 1e-5 and rel_err(stats[1], (refc * refc).sum(0)) < 1e-5

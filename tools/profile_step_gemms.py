@@ -62,8 +62,9 @@ big = torch.empty(1 << 28, device="cuda").normal_()         # 1 GiB scratch for 
 out = torch.empty(1 << 27, device="cuda")
 stat = torch.zeros(2, 4096, dtype=torch.float64, device="cuda")
 rows = []
-TN_ = ["model", "128x128", "64x64", "128x64", "64x128", "3b64x64", "3b128x64", "3b64x128", "r128x128", "r64x64", "r128x64", "r64x128"]
-TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260]   # +16: three LDS buffers; +256: the register-staged kernel
+TN_ = ["model", "128x128", "64x64", "128x64", "64x128", "3b64x64", "3b128x64", "3b64x128", "r128x128", "r64x64", "r128x64", "r64x128",
+       "s+64x64", "s+128x64", "s+64x128", "s+3b64x64"]
+TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260, 34, 35, 36, 50]   # +16: three LDS buffers; +32: M-split (128x128 body + that tail tile); +256: the register-staged kernel
 if PREC != "f32":
     ops.set_gemm_precision(PREC)
 
@@ -92,6 +93,9 @@ for r, n in cnt.items():
     a, b = big.data_ptr(), big.data_ptr() + (1 << 29)
     ts = []
     for tile in TILES:
+        if tile & 32 and (nb_ := batch[0] * batch[1]) * splitk != 1:
+            ts.append(float("inf"))          # M-split needs a single un-split grid
+            continue
         ts.append(timeit(lambda: orig(op, a, b, out.data_ptr(), M, N, K, lda, ldb, ldc, tile=tile, **kw)))
     nb = batch[0] * batch[1]
     fl = 2.0 * M * N * K * nb * (0.75 if op == 4 else 1.0)
