@@ -534,6 +534,52 @@ def lstm_cell_bwd(dh_a, dh_b, dc_in, gates, c, c_prev, dG, dc_prev):
                                        _ptr(c_prev), dG.data_ptr(), dc_prev.data_ptr(), B, H, _st()), "ick_lstm_cell_bwd")
 
 
+def dec_attn_x_fwd(h_top, Wa, Uf, feats, Wc, Xe_t, hW_t, attw_t, ctx_t, x_t):
+    """stage A of the fused decode step (csrc/decoder_fused.hip).  Wa = attention.weight (E, H+E), Wc = attention_combine.weight (E, 2E)."""
+    B, L, E = feats.shape
+    H = Wa.shape[1] - E
+    check(_lib.lib().ick_dec_attn_x_fwd(_ptr(h_top), Wa.data_ptr(), H + E, Uf.data_ptr(), feats.data_ptr(), Wc.data_ptr() + 4 * E,
+                                        2 * E, Xe_t.data_ptr(), hW_t.data_ptr(), attw_t.data_ptr(), ctx_t.data_ptr(),
+                                        x_t.data_ptr(), B, L, E, H, _st()), "ick_dec_attn_x_fwd")
+
+
+def lstm_layer_fwd(inp, h_prev, wih, whh, bih, bhh, c_prev, gates, c_out, h_out, h_drop=None, p_drop=0.0, seed=0):
+    B, H = c_out.shape
+    check(_lib.lib().ick_lstm_layer_fwd(inp.data_ptr(), wih.shape[1], _ptr(h_prev), wih.data_ptr(), whh.data_ptr(), bih.data_ptr(),
+                                        bhh.data_ptr(), _ptr(c_prev), _ptr(gates), c_out.data_ptr(), h_out.data_ptr(), _ptr(h_drop),
+                                        p_drop if h_drop is not None else 0.0, seed, _ptr(_dropout_step["ptr"]), B, H, _st()),
+          "ick_lstm_layer_fwd")
+
+
+def lstm_layer_bwd(dG, WT, carry_h_out, d_inp_out, below=None, p_drop=0.0, seed=0):
+    """stage G.  below = None (layer 0: raw input gradient into d_inp_out) or a dict(carry_h, carry_c, gates, c, c_prev, dG, first)."""
+    B = dG.shape[0]
+    H = dG.shape[1] // 4
+    K1 = WT.shape[0] - H
+    bl = below or {}
+    check(_lib.lib().ick_lstm_layer_bwd(dG.data_ptr(), WT.data_ptr(), _ptr(carry_h_out), _ptr(d_inp_out), _ptr(bl.get("carry_h")),
+                                        _ptr(bl.get("carry_c")), _ptr(bl.get("gates")), _ptr(bl.get("c")), _ptr(bl.get("c_prev")),
+                                        _ptr(bl.get("dG")), int(bl.get("first", 0)), p_drop if below else 0.0, seed,
+                                        _ptr(_dropout_step["ptr"]), B, K1, H, _st()), "ick_lstm_layer_bwd")
+
+
+def dec_attn_x_bwd(dX_t, Wc, attw_t, Uf, hW_t, feats, dUf, dfeats, dhW_t, Wa, dHs_prev, top):
+    """stage Z.  dX_t None: only the top layer's cell adjoint (top = dict(carry_h, carry_c, gates, c, c_prev, dG, first))."""
+    B, L, E = feats.shape
+    H = Wa.shape[1] - E
+    check(_lib.lib().ick_dec_attn_x_bwd(_ptr(dX_t), Wc.data_ptr() + 4 * E, 2 * E, _ptr(attw_t), Uf.data_ptr(), _ptr(hW_t),
+                                        feats.data_ptr(), dUf.data_ptr(), dfeats.data_ptr(), _ptr(dhW_t), Wa.data_ptr(), H + E,
+                                        _ptr(dHs_prev), _ptr(top.get("carry_h")), _ptr(top.get("carry_c")), _ptr(top.get("gates")),
+                                        _ptr(top.get("c")), _ptr(top.get("c_prev")), _ptr(top.get("dG")), int(top.get("first", 0)),
+                                        B, L, E, H, _st()), "ick_dec_attn_x_bwd")
+
+
+def transpose2d(src: torch.Tensor, dst: torch.Tensor) -> None:
+    """dst[c][r] = src[r][c]; dst may be a row-slice of a wider matrix (its row pitch is dst.stride(0))."""
+    rows, cols = src.shape
+    check(_lib.lib().ick_transpose2d(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), rows, cols, _st()), "ick_transpose2d")
+
+
 def argmax_rows(x: torch.Tensor) -> torch.Tensor:
     V = x.shape[-1]
     rows = x.numel() // V

@@ -124,13 +124,22 @@ class _LSTMParams(nn.Module):
             inp = x[:, s].contiguous()
             for l in range(NL):
                 wi, wh, bi, bh = self.layer(l)
-                ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G)
-                ops.gemm_nt(h[l], wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
                 hn, cn = ops.empty(B, H, device=x.device), ops.empty(B, H, device=x.device)
-                ops.lstm_cell_fwd(G, bi, bh, c[l], None, cn, hn)
+                if wi.shape[1] % 16 == 0 and H % 16 == 0:
+                    ops.lstm_layer_fwd(inp, h[l], wi, wh, bi, bh, c[l], None, cn, hn)
+                else:
+                    ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G)
+                    ops.gemm_nt(h[l], wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
+                    ops.lstm_cell_fwd(G, bi, bh, c[l], None, cn, hn)
                 h[l], c[l], inp = hn, cn, hn
             outs[:, s] = h[-1]
         return outs, (torch.stack(h, 0), torch.stack(c, 0))
+
+
+def _fused_step_ok(E: int, H: int) -> bool:
+    """the L + 1-launch decode step (csrc/decoder_fused.hip) needs MFMA-sized widths; every configuration of the
+    reference (128/256, 256/512, 384/768) qualifies — other widths take the generic per-op path."""
+    return E % 16 == 0 and H % 16 == 0 and E <= 1024
 
 
 class DecoderFn(Function):
@@ -160,33 +169,49 @@ class DecoderFn(Function):
         Call = ops.empty(NL, T, B, H, device=dev)
         Gates = ops.empty(NL, T, B, 4 * H, device=dev) if keep else None
         Hd = ops.empty(NL - 1, T, B, H, device=dev) if p_lstm > 0 else None                   # dropped inter-layer inputs
-        # zero-filled arenas: the GEMV-sized GEMMs of the loop are split-K (fp32 atomics) and need zeroed outputs;
-        # one fill per arena instead of one per launch
-        hW = ops.zeros(T, B, E, device=dev)
         attw = ops.empty(T, B, P, device=dev)
         ctxs = ops.empty(T, B, E, device=dev)
-        X = ops.zeros(T, B, E, device=dev)
-        zero_h = ops.zeros(B, H, device=dev)
-        Gall = ops.zeros(T, NL, B, 4 * H, device=dev)
         seeds = [[hnn._next_seed() for _ in range(T)] for _ in range(NL - 1)] if p_lstm > 0 else None
-        for t in range(T):
-            h_top = Hall[NL - 1, t - 1] if t > 0 else zero_h
-            ops.gemm_nt(h_top, Wa.data_ptr(), E, H, H + E, hW[t], zeroed=True)
-            ops.attn_step_fwd(Uf, hW[t], feats, attw[t], ctxs[t])
-            ops.gemm_nt(ctxs[t], Wc.data_ptr() + E * fs, E, E, 2 * E, X[t], residual=Xe[t], zeroed=True)
-            inp = X[t]
-            for l in range(NL):
-                wi, wh, bi, bh = dec.lstm.layer(l)
-                G = Gall[t, l]
-                ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G, zeroed=True)
-                if t > 0:
-                    ops.gemm_nt(Hall[l, t - 1], wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
-                ops.lstm_cell_fwd(G, bi, bh, Call[l, t - 1] if t > 0 else None, Gates[l, t] if keep else None, Call[l, t],
-                                  Hall[l, t])
-                inp = Hall[l, t]
-                if p_lstm > 0 and l < NL - 1:
-                    ops.dropout(Hall[l, t], Hd[l, t], p_lstm, seeds[l][t])
-                    inp = Hd[l, t]
+        fused = _fused_step_ok(E, H)
+        if fused:
+            # L + 1 launches per token (csrc/decoder_fused.hip): stage A per image, then one MFMA GEMM + cell per layer
+            hW = ops.empty(T, B, E, device=dev)
+            X = ops.empty(T, B, E, device=dev)
+            for t in range(T):
+                ops.dec_attn_x_fwd(Hall[NL - 1, t - 1] if t > 0 else None, Wa, Uf, feats, Wc, Xe[t], hW[t], attw[t], ctxs[t], X[t])
+                inp = X[t]
+                for l in range(NL):
+                    wi, wh, bi, bh = dec.lstm.layer(l)
+                    hd = Hd[l, t] if (p_lstm > 0 and l < NL - 1) else None
+                    ops.lstm_layer_fwd(inp, Hall[l, t - 1] if t > 0 else None, wi, wh, bi, bh, Call[l, t - 1] if t > 0 else None,
+                                       Gates[l, t] if keep else None, Call[l, t], Hall[l, t], hd, p_lstm,
+                                       seeds[l][t] if hd is not None else 0)
+                    inp = hd if hd is not None else Hall[l, t]
+        else:
+            # generic path (widths that are not multiples of 16): GEMV-sized split-K GEMMs (fp32 atomics) need zeroed
+            # outputs; one fill per arena instead of one per launch
+            hW = ops.zeros(T, B, E, device=dev)
+            X = ops.zeros(T, B, E, device=dev)
+            zero_h = ops.zeros(B, H, device=dev)
+            Gall = ops.zeros(T, NL, B, 4 * H, device=dev)
+            for t in range(T):
+                h_top = Hall[NL - 1, t - 1] if t > 0 else zero_h
+                ops.gemm_nt(h_top, Wa.data_ptr(), E, H, H + E, hW[t], zeroed=True)
+                ops.attn_step_fwd(Uf, hW[t], feats, attw[t], ctxs[t])
+                ops.gemm_nt(ctxs[t], Wc.data_ptr() + E * fs, E, E, 2 * E, X[t], residual=Xe[t], zeroed=True)
+                inp = X[t]
+                for l in range(NL):
+                    wi, wh, bi, bh = dec.lstm.layer(l)
+                    G = Gall[t, l]
+                    ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G, zeroed=True)
+                    if t > 0:
+                        ops.gemm_nt(Hall[l, t - 1], wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
+                    ops.lstm_cell_fwd(G, bi, bh, Call[l, t - 1] if t > 0 else None, Gates[l, t] if keep else None, Call[l, t],
+                                      Hall[l, t])
+                    inp = Hall[l, t]
+                    if p_lstm > 0 and l < NL - 1:
+                        ops.dropout(Hall[l, t], Hd[l, t], p_lstm, seeds[l][t])
+                        inp = Hd[l, t]
         Hs = Hall[NL - 1]                                                                       # (T,B,H) contiguous
         Z = ops.linear_fwd(Hs.view(T * B, H), W1, b1, act=ACT_RELU)
         Zd, seed_z = Z, 0
@@ -198,7 +223,8 @@ class DecoderFn(Function):
         if keep:
             ctx.dec, ctx.dims = dec, (T, B, P, E, H, NL, V)
             ctx.saved = dict(feats=feats, captions=captions, Uf=Uf, emb=emb, Hall=Hall, Call=Call, Gates=Gates, Hd=Hd, hW=hW,
-                             attw=attw, ctxs=ctxs, X=X, Z=Z, Zd=Zd, seed_z=seed_z, p_drop=p_drop, p_lstm=p_lstm, seeds=seeds)
+                             attw=attw, ctxs=ctxs, X=X, Z=Z, Zd=Zd, seed_z=seed_z, p_drop=p_drop, p_lstm=p_lstm, seeds=seeds,
+                             fused=fused)
         hs_out = Hs
         ctx.mark_non_differentiable(attw)
         return logits, hs_out, attw
@@ -238,32 +264,59 @@ class DecoderFn(Function):
             dHs = ops.zeros(T, B, H, device=dev)
         # ---- BPTT
         DG = ops.empty(NL, T, B, 4 * H, device=dev)
-        dX = ops.zeros(T, B, E, device=dev)                 # zero-filled arenas for the split-K GEMV-sized products
-        dhW = ops.empty(T, B, E, device=dev)
         dUf = ops.zeros(B, P, E, device=dev)
         dfeats = ops.zeros(B, P, E, device=dev)
-        carry = ops.zeros(T, NL, B, H, device=dev)          # carry[t, l]: dL/dh_l flowing INTO step t from step t+1
-        carry_c = [ops.zeros(B, H, device=dev) for _ in range(NL)]
-        d_inp = ops.zeros(T, NL, B, H, device=dev)
-        dctx = ops.zeros(T, B, E, device=dev)
-        for t in range(T - 1, -1, -1):
-            for l in range(NL - 1, -1, -1):
+        dhW = ops.empty(T, B, E, device=dev)
+        if s["fused"]:
+            # L + 1 launches per token: stage G per layer (top first), stage Z per image (csrc/decoder_fused.hip)
+            dX = ops.empty(T, B, E, device=dev)
+            WT = []
+            for l in range(NL):                               # [W_hh | W_ih]^T, once per step
                 wi, wh, _, _ = dec.lstm.layer(l)
-                dh_a = dHs[t] if l == NL - 1 else d_inp[t, l + 1]
-                ops.lstm_cell_bwd(dh_a, carry[t, l] if t < T - 1 else None, carry_c[l] if t < T - 1 else None, Gates[l, t],
-                                  Call[l, t], Call[l, t - 1] if t > 0 else None, DG[l, t], carry_c[l])
+                wt = ops.empty(H + wi.shape[1], 4 * H, device=dev)
+                ops.transpose2d(wh, wt[:H])
+                ops.transpose2d(wi, wt[H:])
+                WT.append(wt)
+            carry_h = [ops.empty(B, H, device=dev) for _ in range(NL)]
+            carry_c = [ops.empty(B, H, device=dev) for _ in range(NL)]
+            top = NL - 1
+
+            def cell(l, t, first):
+                return dict(carry_h=None if first else carry_h[l], carry_c=carry_c[l], gates=Gates[l, t], c=Call[l, t],
+                            c_prev=Call[l, t - 1] if t > 0 else None, dG=DG[l, t], first=first)
+
+            ops.dec_attn_x_bwd(None, Wc, None, s["Uf"], None, s["feats"], dUf, dfeats, None, Wa, dHs[T - 1], cell(top, T - 1, True))
+            for t in range(T - 1, -1, -1):
+                for l in range(top, -1, -1):
+                    ops.lstm_layer_bwd(DG[l, t], WT[l], carry_h[l] if t > 0 else None, dX[t] if l == 0 else None,
+                                       cell(l - 1, t, t == T - 1) if l > 0 else None, s["p_lstm"],
+                                       s["seeds"][l - 1][t] if (l > 0 and s["p_lstm"] > 0) else 0)
+                ops.dec_attn_x_bwd(dX[t], Wc, s["attw"][t], s["Uf"], s["hW"][t], s["feats"], dUf, dfeats, dhW[t], Wa,
+                                   dHs[t - 1] if t > 0 else None, cell(top, t - 1, False) if t > 0 else {})
+        else:
+            dX = ops.zeros(T, B, E, device=dev)             # zero-filled arenas for the split-K GEMV-sized products
+            carry = ops.zeros(T, NL, B, H, device=dev)      # carry[t, l]: dL/dh_l flowing INTO step t from step t+1
+            carry_c = [ops.zeros(B, H, device=dev) for _ in range(NL)]
+            d_inp = ops.zeros(T, NL, B, H, device=dev)
+            dctx = ops.zeros(T, B, E, device=dev)
+            for t in range(T - 1, -1, -1):
+                for l in range(NL - 1, -1, -1):
+                    wi, wh, _, _ = dec.lstm.layer(l)
+                    dh_a = dHs[t] if l == NL - 1 else d_inp[t, l + 1]
+                    ops.lstm_cell_bwd(dh_a, carry[t, l] if t < T - 1 else None, carry_c[l] if t < T - 1 else None, Gates[l, t],
+                                      Call[l, t], Call[l, t - 1] if t > 0 else None, DG[l, t], carry_c[l])
+                    if t > 0:
+                        ops.gemm_nn(DG[l, t], wh.data_ptr(), 4 * H, H, H, carry[t - 1, l], zeroed=True)
+                    if l > 0:
+                        ops.gemm_nn(DG[l, t], wi.data_ptr(), 4 * H, H, H, d_inp[t, l], zeroed=True)
+                        if s["p_lstm"] > 0:
+                            ops.dropout(d_inp[t, l], d_inp[t, l], s["p_lstm"], s["seeds"][l - 1][t])
+                    else:
+                        ops.gemm_nn(DG[0, t], wi.data_ptr(), 4 * H, E, E, dX[t], zeroed=True)
+                ops.gemm_nn(dX[t], Wc.data_ptr() + E * fs, E, E, 2 * E, dctx[t], zeroed=True)
+                ops.attn_step_bwd(dctx[t], s["attw"][t], s["Uf"], s["hW"][t], s["feats"], dUf, dfeats, dhW[t])
                 if t > 0:
-                    ops.gemm_nn(DG[l, t], wh.data_ptr(), 4 * H, H, H, carry[t - 1, l], zeroed=True)
-                if l > 0:
-                    ops.gemm_nn(DG[l, t], wi.data_ptr(), 4 * H, H, H, d_inp[t, l], zeroed=True)
-                    if s["p_lstm"] > 0:
-                        ops.dropout(d_inp[t, l], d_inp[t, l], s["p_lstm"], s["seeds"][l - 1][t])
-                else:
-                    ops.gemm_nn(DG[0, t], wi.data_ptr(), 4 * H, E, E, dX[t], zeroed=True)
-            ops.gemm_nn(dX[t], Wc.data_ptr() + E * fs, E, E, 2 * E, dctx[t], zeroed=True)
-            ops.attn_step_bwd(dctx[t], s["attw"][t], s["Uf"], s["hW"][t], s["feats"], dUf, dfeats, dhW[t])
-            if t > 0:
-                ops.gemm_nn(dhW[t], Wa.data_ptr(), E, H, H + E, carry[t - 1, NL - 1], accumulate=True)
+                    ops.gemm_nn(dhW[t], Wa.data_ptr(), E, H, H + E, carry[t - 1, NL - 1], accumulate=True)
         # ---- deferred weight gradients, batched over all steps
         for l in range(NL):
             wi, wh, bi, bh = dec.lstm.layer(l)
@@ -364,18 +417,25 @@ class LSTMDecoder(nn.Module):
         hW, w, cx = ops.empty(B, E, device=dev), ops.empty(B, P, device=dev), ops.empty(B, E, device=dev)
         xe, x, G, z = ops.empty(B, E, device=dev), ops.empty(B, E, device=dev), ops.empty(B, 4 * H, device=dev), ops.empty(B, E, device=dev)
         W1, W2 = self.output_projection[0], self.output_projection[3]
+        fused = _fused_step_ok(E, H)
         for t in range(max_length):
             emb = ops.embedding_fwd(tok, self.embedding.weight)
             ops.gemm_nt(emb, Wc.data_ptr(), E, E, 2 * E, xe, bias=self.attention_combine.bias)
-            ops.gemm_nt(h[NL - 1], Wa.data_ptr(), E, H, H + E, hW)
-            ops.attn_step_fwd(Uf, hW, feats, w, cx)
-            ops.gemm_nt(cx, Wc.data_ptr() + E * 4, E, E, 2 * E, x, residual=xe)
+            if fused:
+                ops.dec_attn_x_fwd(h[NL - 1], Wa, Uf, feats, Wc, xe, hW, w, cx, x)
+            else:
+                ops.gemm_nt(h[NL - 1], Wa.data_ptr(), E, H, H + E, hW)
+                ops.attn_step_fwd(Uf, hW, feats, w, cx)
+                ops.gemm_nt(cx, Wc.data_ptr() + E * 4, E, E, 2 * E, x, residual=xe)
             inp = x
             for l in range(NL):
                 wi, wh, bi, bh = self.lstm.layer(l)
-                ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G)
-                ops.gemm_nt(h[l], wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
-                ops.lstm_cell_fwd(G, bi, bh, c[l], None, cn[l], hn[l])
+                if fused:
+                    ops.lstm_layer_fwd(inp, h[l], wi, wh, bi, bh, c[l], None, cn[l], hn[l])
+                else:
+                    ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G)
+                    ops.gemm_nt(h[l], wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
+                    ops.lstm_cell_fwd(G, bi, bh, c[l], None, cn[l], hn[l])
                 h[l], hn[l] = hn[l], h[l]
                 c[l], cn[l] = cn[l], c[l]
                 inp = h[l]

@@ -165,6 +165,31 @@ int ick_lstm_cell_fwd(const float* G, const float* b_ih, const float* b_hh, cons
 int ick_lstm_cell_bwd(const float* dh_a, const float* dh_b, const float* dc_in, const float* gates, const float* c,
                       const float* c_prev, float* dG, float* dc_prev, int B, int H, void* stream);
 int ick_argmax_rows(const float* x, int64_t* ids, int64_t rows, int V, int64_t ld, void* stream); /* greedy token (student_model.py:369) */
+/* The decode step as L + 1 launches per token and direction (csrc/decoder_fused.hip) — the loop body student_model.py:232-251:
+ * stage A per image: hW = W_h h_top (Wh = attention.weight[:, :H], row pitch ldwa; h_top NULL = zero state), scores / softmax /
+ * context (:186-201), x = W_c2 ctx + Xe (Wc2 = attention_combine.weight[:, E:], pitch ldwc; Xe = the hoisted embedding half + bias);
+ * stage L per layer: gates = [inp ; h_prev] [W_ih | W_hh]^T + b_ih + b_hh -> LSTM cell (:244), optional inter-layer dropout copy. */
+int ick_dec_attn_x_fwd(const float* h_top, const float* Wh, int64_t ldwa, const float* Uf, const float* feats, const float* Wc2,
+                       int64_t ldwc, const float* Xe, float* hW_out, float* w_out, float* ctx_out, float* x_out, int B, int L, int E,
+                       int H, void* stream);
+int ick_lstm_layer_fwd(const float* inp, int K1, const float* h_prev, const float* Wih, const float* Whh, const float* bih,
+                       const float* bhh, const float* c_prev, float* gates, float* c_out, float* h_out, float* h_drop, float p_drop,
+                       uint64_t seed, const int64_t* step, int B, int H, void* stream);
+/* adjoints.  Stage G per layer: [carry into h(t-1) | input gradient] = dG [W_hh | W_ih], WT = that matrix transposed,
+ * [(H + K1)][4H] (ick_transpose2d, once per step); carry_h_out NULL at t = 0; the input gradient is stored raw (d_inp_out: layer 0)
+ * or run through the inter-layer dropout mask + the cell adjoint of the layer below (below_*; below_first = last token).
+ * Stage Z per image: dctx = W_c2^T dX, attention adjoint (dUf / dfeats accumulated, dhW stored), then the TOP layer's cell adjoint for
+ * token t-1 with dh = dHs_prev + top_carry_h + W_h^T dhW.  dX NULL: cell adjoint only (the last token); dHs_prev NULL: t = 0. */
+int ick_lstm_layer_bwd(const float* dG, const float* WT, float* carry_h_out, float* d_inp_out, const float* below_carry_h,
+                       float* below_carry_c, const float* below_gates, const float* below_c, const float* below_c_prev,
+                       float* below_dG, int below_first, float p_drop, uint64_t seed, const int64_t* step, int B, int K1, int H,
+                       void* stream);
+int ick_dec_attn_x_bwd(const float* dX, const float* Wc2, int64_t ldwc, const float* w, const float* Uf, const float* hW,
+                       const float* feats, float* dUf, float* dfeats, float* dhW_out, const float* Wh, int64_t ldwa,
+                       const float* dHs_prev, const float* top_carry_h, float* top_carry_c, const float* top_gates,
+                       const float* top_c, const float* top_c_prev, float* top_dG, int top_first, int B, int L, int E, int H,
+                       void* stream);
+int ick_transpose2d(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols, void* stream); /* dst[c][r] = src[r][c] */
 int ick_beam_topk(const float* logits, const float* scores, int Bl, int V, int k, float* out_vals, int64_t* out_idx,
                   void* stream); /* scores[b] + log_softmax(logits[b]) -> k best flat (b*V+v) candidates (teacher_model.py:170-179) */
 
