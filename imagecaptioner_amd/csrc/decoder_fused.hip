@@ -54,19 +54,28 @@ struct Drop {
 constexpr int ANT = 1024;   // threads of a per-image workgroup (16 waves)
 constexpr int GNT = 256;    // threads of a skinny-GEMM workgroup (4 waves)
 
-// out[e] = sum_k v[k] * W[e][k] for e in [0, n_out): one wave per output (lanes stride k by float4), v in LDS
+// out[e] = sum_k v[k] * W[e][k] for e in [0, n_out), n_out % 4 == 0: one wave per FOUR outputs at a time (lanes stride k by
+// float4), v in LDS.  Four rows per trip keep 4-8 independent 16-byte loads in flight per lane: the weights come from L2
+// (every image's workgroup re-reads them), and one row per trip left the wave waiting out a full L2 round trip per output
+// (34 us for the stage instead of the ~13 us of its attention part).
 __device__ __forceinline__ void matvec_rows(const float* __restrict__ W, long ldw, const float* v, int K, int n_out,
                                             float* out_lds, int wave, int lane, int nwaves) {
-  for (int e = wave; e < n_out; e += nwaves) {
+  for (int e = wave * 4; e < n_out; e += nwaves * 4) {
     const float* wr = W + (long)e * ldw;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     for (int k = lane * 4; k < K; k += 256) {
-      const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+      const float4 a = *reinterpret_cast<const float4*>(wr + k);
+      const float4 b = *reinterpret_cast<const float4*>(wr + ldw + k);
+      const float4 c = *reinterpret_cast<const float4*>(wr + 2 * ldw + k);
+      const float4 d = *reinterpret_cast<const float4*>(wr + 3 * ldw + k);
       const float4 v4 = *reinterpret_cast<const float4*>(v + k);
-      s = fmaf(w4.x, v4.x, s); s = fmaf(w4.y, v4.y, s); s = fmaf(w4.z, v4.z, s); s = fmaf(w4.w, v4.w, s);
+      s0 = fmaf(a.x, v4.x, s0); s0 = fmaf(a.y, v4.y, s0); s0 = fmaf(a.z, v4.z, s0); s0 = fmaf(a.w, v4.w, s0);
+      s1 = fmaf(b.x, v4.x, s1); s1 = fmaf(b.y, v4.y, s1); s1 = fmaf(b.z, v4.z, s1); s1 = fmaf(b.w, v4.w, s1);
+      s2 = fmaf(c.x, v4.x, s2); s2 = fmaf(c.y, v4.y, s2); s2 = fmaf(c.z, v4.z, s2); s2 = fmaf(c.w, v4.w, s2);
+      s3 = fmaf(d.x, v4.x, s3); s3 = fmaf(d.y, v4.y, s3); s3 = fmaf(d.z, v4.z, s3); s3 = fmaf(d.w, v4.w, s3);
     }
-    s = wave_sum(s);
-    if (lane == 0) out_lds[e] = s;
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if (lane == 0) { out_lds[e] = s0; out_lds[e + 1] = s1; out_lds[e + 2] = s2; out_lds[e + 3] = s3; }
   }
 }
 
@@ -314,9 +323,16 @@ __global__ __launch_bounds__(ANT) void dec_attn_x_bwd_kernel(const float* __rest
     for (int q = tid; q < E; q += ANT) dhw[q] = dX[(long)b * E + q];     // dX row staged in the dhW slot for now
     __syncthreads();
     if (jg < ng) {
-      float a = 0.f;
-      for (int r = jg; r < E; r += ng) a = fmaf(dhw[r], Wc2[(long)r * ldwc + e], a);
-      part[jg * E + e] = a;
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;            // 4 independent chains: the row loads come from L2
+      int r = jg;
+      for (; r + 3 * ng < E; r += 4 * ng) {
+        const float w0 = Wc2[(long)r * ldwc + e], w1 = Wc2[(long)(r + ng) * ldwc + e];
+        const float w2 = Wc2[(long)(r + 2 * ng) * ldwc + e], w3 = Wc2[(long)(r + 3 * ng) * ldwc + e];
+        a0 = fmaf(dhw[r], w0, a0); a1 = fmaf(dhw[r + ng], w1, a1);
+        a2 = fmaf(dhw[r + 2 * ng], w2, a2); a3 = fmaf(dhw[r + 3 * ng], w3, a3);
+      }
+      for (; r < E; r += ng) a0 = fmaf(dhw[r], Wc2[(long)r * ldwc + e], a0);
+      part[jg * E + e] = (a0 + a1) + (a2 + a3);
     }
     for (int j = tid; j < L; j += ANT) wl[j] = w[(long)b * L + j];
     __syncthreads();
@@ -372,9 +388,16 @@ __global__ __launch_bounds__(ANT) void dec_attn_x_bwd_kernel(const float* __rest
       for (int k0 = 0; k0 < H; k0 += ANT) {                       // one trip unless H > 1024
         const int k = k0 + tid % (H <= ANT ? H : ANT), g = H <= ANT ? tid / H : 0;
         if (g < gh && k < H) {
-          float a = 0.f;
-          for (int q = g; q < E; q += gh) a = fmaf(dhw[q], Wh[(long)q * ldwa + k], a);
-          part[g * (H <= ANT ? H : ANT) + (k - k0)] = a;
+          float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+          int q = g;
+          for (; q + 3 * gh < E; q += 4 * gh) {
+            const float w0 = Wh[(long)q * ldwa + k], w1 = Wh[(long)(q + gh) * ldwa + k];
+            const float w2 = Wh[(long)(q + 2 * gh) * ldwa + k], w3 = Wh[(long)(q + 3 * gh) * ldwa + k];
+            a0 = fmaf(dhw[q], w0, a0); a1 = fmaf(dhw[q + gh], w1, a1);
+            a2 = fmaf(dhw[q + 2 * gh], w2, a2); a3 = fmaf(dhw[q + 3 * gh], w3, a3);
+          }
+          for (; q < E; q += gh) a0 = fmaf(dhw[q], Wh[(long)q * ldwa + k], a0);
+          part[g * (H <= ANT ? H : ANT) + (k - k0)] = (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
         const int kk = k0 + tid;

@@ -4,6 +4,7 @@
 // contiguous (channel / feature) axis, grid-stride loops capped at ~2048 workgroups, wave64
 // shuffles for reductions.
 #include "ick_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -233,7 +234,7 @@ struct d4 { double x, y, z, w; };
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                      const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ inv, double* __restrict__ sum_g,
-                                     double* __restrict__ sum_gx, long M, int C) {
+                                     double* __restrict__ sum_gx, int copies, long stride, long M, int C) {
   const int C4 = C >> 2;
   const int lanes = C4 < NT ? C4 : NT;     // threads along channels
   const int rows = NT / lanes;             // threads along rows
@@ -291,7 +292,10 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
         dx.x += b.x; dx.y += b.y; dx.z += b.z; dx.w += b.w;
       }
       const float4 iv = reinterpret_cast<const float4*>(inv)[c4];
-      double* sg = sum_g + c4 * 4; double* sx = sum_gx + c4 * 4;
+      // up to 1024 row-blocks add into the same 2 x C addresses: spread them over `copies` accumulator rows (the apply
+      // pass folds them) — same-address fp64 atomics serialise in L2 and were most of this kernel's time
+      const long co = (long)(blockIdx.y % copies) * stride;
+      double* sg = sum_g + co + c4 * 4; double* sx = sum_gx + co + c4 * 4;
       atomicAdd(sg + 0, dg.x); atomicAdd(sg + 1, dg.y); atomicAdd(sg + 2, dg.z); atomicAdd(sg + 3, dg.w);
       atomicAdd(sx + 0, dx.x * iv.x); atomicAdd(sx + 1, dx.y * iv.y); atomicAdd(sx + 2, dx.z * iv.z); atomicAdd(sx + 3, dx.w * iv.w);
     }
@@ -299,17 +303,25 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
   }
 }
 
-// BN backward pass 2: dx = gamma*inv*(g - sum_g/M - xhat*sum_gx/M); optionally also writes g (the gradient that
+// BN backward pass 2a: fold the accumulator copies once — coef = {sum_g / M, sum_gx / M} as floats for the apply pass, and the
+// parameter gradients, which are the two reductions themselves: dgamma += sum(g * xhat), dbeta += sum(g).
+__global__ void bn_bwd_fold_kernel(const double* __restrict__ sum_g, const double* __restrict__ sum_gx, int copies, long stride,
+                                   double invM, float* __restrict__ coef, float* __restrict__ dgamma, float* __restrict__ dbeta, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double sg = fold_copies(sum_g, c, copies, stride), sx = fold_copies(sum_gx, c, copies, stride);
+  coef[c] = (float)(sg * invM);
+  coef[C + c] = (float)(sx * invM);
+  if (dgamma) { dgamma[c] += (float)sx; dbeta[c] += (float)sg; }
+}
+
+// BN backward pass 2b: dx = gamma*inv*(g - mean_g - xhat*mean_gx); optionally also writes g (the gradient that
 // flows on into the residual branch).  In eval mode (use_batch_stats == 0): dx = gamma*inv*g.
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                     const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ inv, const float* __restrict__ gamma,
-                                    const double* __restrict__ sum_g, const double* __restrict__ sum_gx, double invM,
-                                    float* __restrict__ dx, float* __restrict__ gout, long total4, int C4,
-                                    int use_batch_stats, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  // the parameter gradients are the two reductions themselves: dgamma += sum(g*xhat), dbeta += sum(g)
-  if (dgamma && blockIdx.x == 0)
-    for (int c = threadIdx.x; c < 4 * C4; c += blockDim.x) { dgamma[c] += (float)sum_gx[c]; dbeta[c] += (float)sum_g[c]; }
+                                    const float* __restrict__ coef, float* __restrict__ dx, float* __restrict__ gout,
+                                    long total4, int C4, int use_batch_stats) {
   // the grid stride is a multiple of C4 (launcher), so a thread's 4 channels never change: per-channel terms once
   const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const int c = (int)(i0 % C4);
@@ -318,9 +330,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
   float4 mu = make_float4(0, 0, 0, 0), mg = mu, mx = mu;
   if (use_batch_stats) {
     mu = reinterpret_cast<const float4*>(mean)[c];
-    const double* sg = sum_g + 4 * c; const double* sx = sum_gx + 4 * c;
-    mg = make_float4((float)(sg[0] * invM), (float)(sg[1] * invM), (float)(sg[2] * invM), (float)(sg[3] * invM));
-    mx = make_float4((float)(sx[0] * invM), (float)(sx[1] * invM), (float)(sx[2] * invM), (float)(sx[3] * invM));
+    mg = reinterpret_cast<const float4*>(coef)[c];
+    mx = reinterpret_cast<const float4*>(coef)[C4 + c];
   }
   for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
     float4 g = reinterpret_cast<const float4*>(dy)[i];
@@ -631,34 +642,44 @@ int ick_scale_shift_act(const float* x, const float* scale, const float* shift, 
 }
 
 int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                      double* sum_g, double* sum_gx, long M, int C, void* stream) {
+                      double* sum_g, double* sum_gx, int copies, int64_t stride, long M, int C, void* stream) {
+  ICK_REQUIRE(copies >= 1 && (copies == 1 || stride >= C), "ick_bn_bwd_reduce: copies >= 1, stride >= C");
   ICK_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && C % 4 == 0 && M > 0, "ick_bn_bwd_reduce: bad arguments");
   const int C4 = C / 4;
   const int lanes = C4 < NT ? C4 : NT;
   ICK_REQUIRE(NT % lanes == 0, "ick_bn_bwd_reduce: C/4=%d must divide %d or be a multiple of it", C4, NT);
   const int rows = NT / lanes;
   const int gx = (C4 + lanes - 1) / lanes;
-  long gy = (M + rows * 16 - 1) / (rows * 16);   // ~16 rows per thread
-  if (gy > 1024) gy = 1024;
+  // Grid: ~200 workgroups in all.  Every workgroup ends with 2 x 4 x lanes fp64 atomics onto the same 2 x C addresses and
+  // those — not the 12 B/element stream — set the time: measured (tools/bench_bn.py, M = 12544, C = 1024) 123 us with 3136
+  // row-blocks, 55 us with 784, 27 us (5.7 TB/s) with 196; fewer than ~100 starves the memory system again.
+  static const int target = [] { const char* e = getenv("ICK_BN_BWD_BLOCKS"); return e ? atoi(e) : 200; }();   // A/B runs
+  long gy = target / gx;
+  const long gmax = (M + rows * 4 - 1) / (rows * 4);          // at least one 4-row trip per thread
+  if (gy > gmax) gy = gmax;
   if (gy < 1) gy = 1;
-  ICK_LAUNCH(bn_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, M, C);
+  ICK_LAUNCH(bn_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, copies, (long)stride, M, C);
   return ick::launch_status("bn_bwd_reduce");
 }
 
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                     const float* gamma, const double* sum_g, const double* sum_gx, float* dx, float* g_out, long M, int C,
-                     int use_batch_stats, float* dgamma, float* dbeta, void* stream) {
+                     const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws,
+                     float* dx, float* g_out, long M, int C, int use_batch_stats, float* dgamma, float* dbeta, void* stream) {
+  if (copies < 1) copies = 1;
   ICK_REQUIRE(dy && x && mean && invstd && gamma && dx && C % 4 == 0 && M > 0, "ick_bn_bwd_apply: bad arguments");
   ICK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "ick_bn_bwd_apply: dgamma and dbeta go together");
-  ICK_REQUIRE(!use_batch_stats || (sum_g && sum_gx), "ick_bn_bwd_apply: batch statistics need the two sums");
+  ICK_REQUIRE(!use_batch_stats || (sum_g && sum_gx && coef_ws), "ick_bn_bwd_apply: batch statistics need the two sums and the 2*C workspace");
   const int C4 = C / 4;
   ICK_REQUIRE(C4 <= NT ? NT % C4 == 0 : C4 % NT == 0, "ick_bn_bwd_apply: C/4=%d must divide %d or be a multiple of it", C4, NT);
+  if (use_batch_stats)
+    ICK_LAUNCH(bn_bwd_fold_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum_g, sum_gx, copies, (long)stride, 1.0 / (double)M,
+               coef_ws, dgamma, dbeta, C);
   const long total4 = M * C4;
   int grid = grid_for(total4);
   const int q = C4 > NT ? C4 / NT : 1;          // grid * NT must be a multiple of C4: a thread keeps its channels
   grid = (grid + q - 1) / q * q;
-  ICK_LAUNCH(bn_bwd_apply_kernel, dim3(grid), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, sum_g,
-                     sum_gx, 1.0 / (double)M, dx, g_out, total4, C4, use_batch_stats, dgamma, dbeta);
+  ICK_LAUNCH(bn_bwd_apply_kernel, dim3(grid), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, coef_ws, dx, g_out, total4, C4,
+             use_batch_stats);
   return ick::launch_status("bn_bwd_apply");
 }
 

@@ -360,7 +360,7 @@ def bottleneck_backward(blk: Bottleneck, r: dict, d, need_in: bool, sums_arena=N
         C = bn.weight.numel()
         return ops.bn_bwd(dyv, ymask, raw, mean, inv, bn.weight, grad_buf(bn.weight) if bn.weight.requires_grad else None,
                           grad_buf(bn.bias) if bn.weight.requires_grad else None, want_g, True,
-                          sums=sums_arena.take(2, C) if sums_arena is not None else None)
+                          sums=sums_arena.take(2 * ops.BN_BWD_COPIES, C).view(2, ops.BN_BWD_COPIES, C) if sums_arena is not None else None)
 
     def wgrad(conv, dyv, xin):
         if conv.weight.requires_grad:
@@ -436,7 +436,7 @@ class ResNetTrunkFn(Function):
             return (None,) * len(ctx.needs_input_grad)
         d = _c(dy).view(recs[-1]["out"].shape)
         state = dict(blocks=blocks, first=first, recs=recs, d=d, next=len(blocks) - 1,
-                     sums=_Arena(2 * _bn_channels(blocks[first:]), torch.float64, d.device))
+                     sums=_Arena(2 * ops.BN_BWD_COPIES * _bn_channels(blocks[first:]), torch.float64, d.device))
         if _TRUNK_DEFER["on"]:
             # data-parallel step: the trainer runs the trunk's backward itself, stage by stage, so that the gradient
             # buckets of everything ABOVE the trunk are already on the wire while layer4 / layer3 are still computing

@@ -415,20 +415,26 @@ def scale_shift_act(x, scale, shift, residual, relu: bool, out=None):
     return y
 
 
+BN_BWD_COPIES = int(__import__("os").environ.get("ICK_BN_BWD_COPIES", "8"))      # accumulator rows of the BatchNorm-backward sums (spreads same-address fp64 atomics)
+
+
 def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batch_stats: bool = True, sums=None):
     """Backward through [relu](bn(x)[+res]).  dy: grad wrt the block output; y_mask: that output (relu mask) or None.
     Accumulates dgamma/dbeta (+=) inside the apply kernel; returns (dx, g) with g = masked dy (gradient of the
-    residual branch) if want_g.  `sums`: a zeroed (2,C) slice of a caller-owned arena (saves one fill per BN)."""
+    residual branch) if want_g.  `sums`: a zeroed (2, R, C) fp64 slice of a caller-owned arena (saves one fill per BN)."""
     C = x.shape[-1]
     M = x.numel() // C
     if sums is None:
-        sums = torch.zeros(2, C, dtype=torch.float64, device=x.device)
+        sums = torch.zeros(2, BN_BWD_COPIES, C, dtype=torch.float64, device=x.device)
+    R = sums.shape[1] if sums.dim() == 3 else 1
     check(_lib.lib().ick_bn_bwd_reduce(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                       sums[0].data_ptr(), sums[1].data_ptr(), M, C, _st()), "ick_bn_bwd_reduce")
+                                       sums[0].data_ptr(), sums[1].data_ptr(), R, C, M, C, _st()), "ick_bn_bwd_reduce")
     dx = torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
+    coef = empty(2, C, device=x.device)
     check(_lib.lib().ick_bn_bwd_apply(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                      gamma.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), dx.data_ptr(), _ptr(g),
+                                      gamma.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), R, C, coef.data_ptr(),
+                                      dx.data_ptr(), _ptr(g),
                                       M, C, int(batch_stats), _ptr(dgamma), _ptr(dbeta), _st()), "ick_bn_bwd_apply")
     return dx, g
 

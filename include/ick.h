@@ -125,10 +125,10 @@ int ick_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 int ick_scale_shift_act(const float* x, const float* scale, const float* shift, const float* residual, float* y,
                         int64_t M, int C, int relu, void* stream);                          /* y = [relu](x*scale+shift [+ residual]) */
 int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                      double* sum_g, double* sum_gx, int64_t M, int C, void* stream);        /* += sum(g), sum(g*xhat) in fp64 (the reference's CPU batch_norm backward reduces in double); g = dy*(y>0) if y */
+                      double* sum_g, double* sum_gx, int copies, int64_t stride, int64_t M, int C, void* stream); /* += sum(g), sum(g*xhat) in fp64, spread over `copies` accumulator rows `stride` elements apart (row-block b adds into row b %% copies; ick_bn_bwd_apply folds them) (the reference's CPU batch_norm backward reduces in double); g = dy*(y>0) if y */
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                     const float* gamma, const double* sum_g, const double* sum_gx, float* dx, float* g_out,
-                     int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, void* stream); /* dgamma/dbeta (optional) += the two sums */
+                     const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws /* [2*C] scratch */,
+                     float* dx, float* g_out, int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, void* stream); /* dgamma/dbeta (optional) += the two sums */
 int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                        float* y, float* save_mean, float* save_invstd, int64_t M, int C, int relu, void* stream); /* bn_finalize + scale_shift_act in one pass */
