@@ -36,7 +36,7 @@ def mfma_peak(precision: str, gflop_student: float = GFLOP_STUDENT):
     """Roofline denominator for the step: the teacher always runs on the fp32 MFMA; the student's contractions run on
     the fp32 MFMA ("f32"), on the bf16 MFMA ("bf16") or as 3 bf16 MFMAs per product ("bf16x3").  The blended peak
     is total FLOPs / (time of each part at its own MFMA peak)."""
-    ps = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 3}[precision]
+    ps = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "fp16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 3}[precision]
     return (GFLOP_TEACHER + gflop_student) / (GFLOP_TEACHER / PEAK_F32_MFMA_TF + gflop_student / ps)
 BATCH = 64
 VOCAB, T1 = 5000, 16
@@ -264,7 +264,7 @@ def main():
                     help="only time the dominant kernel in isolation (for the matching rocprofv3 --kernel-trace --stats run)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (bf16 step, cfg2 decode) at N=1")
     ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream instead of a parallel graph branch")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "bf16x3"],
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "fp16", "bf16x3"],
                     help="student/projector GEMM arithmetic (teacher stays fp32 as in the reference); f32 = parity regime")
     args = ap.parse_args()
 
@@ -315,6 +315,7 @@ def main():
         traffic, traffic_src = measured_traffic(args.batch)
         peak = mfma_peak(args.precision, gflop_img - GFLOP_TEACHER)
         dtype = {"f32": "f32", "bf16": "bf16 student (fp32 accumulate, fp32 master weights) + f32 teacher",
+                 "fp16": "fp16 student (fp32 accumulate, fp32 master weights, device GradScaler) + f32 teacher",
                  "bf16x3": "split-bf16x3 student + f32 teacher"}[args.precision]
         out = {
             "metric": "images/sec KD train step (teacher+student fwd + KD loss + bwd)", "value": round(ips, 2),
@@ -338,12 +339,16 @@ def main():
             out["roofline"]["dominant_kernel"] = dominant_kernel(dev)
             # secondary measurements, same process: the reference's mixed-precision regime and BASELINE configs[1]
             if args.precision == "f32":
-                ips2, dt2, dev2, loss2 = run_kd(args, "bf16", dev, rank, world, log)
-                ach2 = GFLOP_PER_IMAGE * args.batch / (dev2 / args.steps)
-                out["mixed_precision"] = {"dtype": "bf16 student (fp32 accumulate, fp32 master weights) + f32 teacher",
-                                          "value": round(ips2, 2), "unit": "images/s", "ms_per_step": round(dt2 / args.steps * 1e3, 3),
-                                          "final_loss": round(loss2["total_loss"], 5), "achieved_TFLOPs": round(ach2, 2),
-                                          "blended_peak_TFLOPs": round(mfma_peak("bf16"), 1)}
+                # the reference's AMP regime (train_student_kd.py:239,271: fp16 autocast + GradScaler), then its bf16 twin
+                out["mixed_precision"] = {}
+                for prec2, label in (("fp16", "fp16 student (fp32 accumulate, fp32 master weights, device GradScaler 2^16) + f32 teacher"),
+                                     ("bf16", "bf16 student (fp32 accumulate, fp32 master weights) + f32 teacher")):
+                    ips2, dt2, dev2, loss2 = run_kd(args, prec2, dev, rank, world, log)
+                    ach2 = GFLOP_PER_IMAGE * args.batch / (dev2 / args.steps)
+                    out["mixed_precision"][prec2] = {"dtype": label, "value": round(ips2, 2), "unit": "images/s",
+                                                     "ms_per_step": round(dt2 / args.steps * 1e3, 3),
+                                                     "final_loss": round(loss2["total_loss"], 5), "achieved_TFLOPs": round(ach2, 2),
+                                                     "blended_peak_TFLOPs": round(mfma_peak(prec2), 1)}
             out["cfg2"] = run_cfg2(dev, log)
         if world == 1 and not args.no_cpu_baseline:
             log(f"GPU: {ips:.1f} images/s; timing the CPU baseline on a bounded sample ...")

@@ -33,6 +33,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// TERMS == 2: fp16 instead of bf16 (v_mfma_f32_32x32x16_f16) — same 16-bit LDS images, different rounding + MFMA
+template <int TERMS> struct Half16 { using x8 = bf16x8; using x4 = bf16x4; };
+template <> struct Half16<2> { using x8 = f16x8; using x4 = f16x4; };
+template <int TERMS, typename V>
+__device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
+  if constexpr (TERMS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
@@ -45,22 +55,24 @@ template <bool KC, int BX>
 constexpr int img_elems() { return KC ? BX * KCP : BK * (BX + 32); }
 
 // 4 fp32 -> 4 bf16 (round to nearest even) stored as 8 bytes; with SPLIT also the bf16 of the rounding residual
-template <bool SPLIT>
+template <int TERMS>
 __device__ __forceinline__ void store4(u16* dst, int lo_off, float4 v) {
+  using h4 = typename Half16<TERMS>::x4;
   const f32x4 x = {v.x, v.y, v.z, v.w};
-  const bf16x4 h = __builtin_convertvector(x, bf16x4);
-  *reinterpret_cast<bf16x4*>(dst) = h;
-  if constexpr (SPLIT) {
+  const h4 h = __builtin_convertvector(x, h4);
+  *reinterpret_cast<h4*>(dst) = h;
+  if constexpr (TERMS == 3) {
     const f32x4 r = x - __builtin_convertvector(h, f32x4);
-    *reinterpret_cast<bf16x4*>(dst + lo_off) = __builtin_convertvector(r, bf16x4);
+    *reinterpret_cast<h4*>(dst + lo_off) = __builtin_convertvector(r, h4);
   }
 }
 
-__device__ __forceinline__ bf16x8 tr_read8(const u16* p, int row_pitch) {
+template <typename H8>
+__device__ __forceinline__ H8 tr_read8(const u16* p, int row_pitch) {
   typedef __attribute__((address_space(3))) s16x4* lds_p;
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p));
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(p + 4 * row_pitch));
-  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+  return __builtin_bit_cast(H8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
 template <int OP, int BM, int BN, int TERMS>
@@ -281,9 +293,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
       float4 v = keep_if(ra[i], (amask >> i) & 1u);
       if constexpr (AK) {
         if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) v = ktail(v, kq, kend);
-        store4<SPLIT>(Ab + (i * 32 + (tid >> 3)) * KCP + a_k4, A_SZ, v);
+        store4<TERMS>(Ab + (i * 32 + (tid >> 3)) * KCP + a_k4, A_SZ, v);
       } else {
-        store4<SPLIT>(Ab + (i * A_KR + tid / A_TPK) * A_XP + (tid % A_TPK) * 4, A_SZ, v);
+        store4<TERMS>(Ab + (i * A_KR + tid / A_TPK) * A_XP + (tid % A_TPK) * 4, A_SZ, v);
       }
     }
 #pragma unroll
@@ -291,9 +303,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
       float4 v = keep_if(rb[i], (bmask >> i) & 1u);
       if constexpr (BKc) {
         v = ktail(v, kq, kend);
-        store4<SPLIT>(Bb + (i * 32 + (tid >> 3)) * KCP + a_k4, B_SZ, v);
+        store4<TERMS>(Bb + (i * 32 + (tid >> 3)) * KCP + a_k4, B_SZ, v);
       } else {
-        store4<SPLIT>(Bb + (i * B_KR + tid / B_TPK) * B_XP + (tid % B_TPK) * 4, B_SZ, v);
+        store4<TERMS>(Bb + (i * B_KR + tid / B_TPK) * B_XP + (tid % B_TPK) * 4, B_SZ, v);
       }
     }
   };
@@ -301,20 +313,21 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
   // MFMA operand fragment of k-step s (16 k): lane l holds X[row l&31][k = 8*(l>>5) + 0..7]
   const int frow = lane & 31, fk = lane >> 5;
   const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;   // transposed read: group, block row, 4-column piece
-  auto frag_a = [&](int buf, int img, int s, int i) -> bf16x8 {
+  using h8 = typename Half16<TERMS>::x8;
+  auto frag_a = [&](int buf, int img, int s, int i) -> h8 {
     const u16* base = lds + buf * BUF + img * A_SZ;
     if constexpr (AK) {
-      return *reinterpret_cast<const bf16x8*>(base + (wm * WM + i * 32 + frow) * KCP + s * 16 + fk * 8);
+      return *reinterpret_cast<const h8*>(base + (wm * WM + i * 32 + frow) * KCP + s * 16 + fk * 8);
     } else {
-      return tr_read8(base + (s * 16 + (tg >> 1) * 8 + tq) * A_XP + wm * WM + i * 32 + (tg & 1) * 16 + tp * 4, A_XP);
+      return tr_read8<h8>(base + (s * 16 + (tg >> 1) * 8 + tq) * A_XP + wm * WM + i * 32 + (tg & 1) * 16 + tp * 4, A_XP);
     }
   };
-  auto frag_b = [&](int buf, int img, int s, int j) -> bf16x8 {
+  auto frag_b = [&](int buf, int img, int s, int j) -> h8 {
     const u16* base = lds + buf * BUF + IMGS * A_SZ + img * B_SZ;
     if constexpr (BKc) {
-      return *reinterpret_cast<const bf16x8*>(base + (wn * WN + j * 32 + frow) * KCP + s * 16 + fk * 8);
+      return *reinterpret_cast<const h8*>(base + (wn * WN + j * 32 + frow) * KCP + s * 16 + fk * 8);
     } else {
-      return tr_read8(base + (s * 16 + (tg >> 1) * 8 + tq) * B_XP + wn * WN + j * 32 + (tg & 1) * 16 + tp * 4, B_XP);
+      return tr_read8<h8>(base + (s * 16 + (tg >> 1) * 8 + tq) * B_XP + wn * WN + j * 32 + (tg & 1) * 16 + tp * 4, B_XP);
     }
   };
 
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) fetch(kt + 1);
-    bf16x8 av[2][IMGS][TM], bv[2][IMGS][TN];
+    h8 av[2][IMGS][TM], bv[2][IMGS][TN];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -352,10 +365,10 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           if constexpr (SPLIT) {   // small terms first
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][1][i], bv[s][0][j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][0][i], bv[s][1][j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma16<TERMS>(av[s][1][i], bv[s][0][j], acc[i][j]);
+            acc[i][j] = mfma16<TERMS>(av[s][0][i], bv[s][1][j], acc[i][j]);
           }
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[s][0][i], bv[s][0][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma16<TERMS>(av[s][0][i], bv[s][0][j], acc[i][j]);
         }
     if (kt + 1 < nkt) stash(buf ^ 1, kt + 1);
     __syncthreads();
@@ -492,7 +505,7 @@ int launch(const P& p0, int nz, hipStream_t st) {
 // The split (TERMS == 3) 128x128 tile would need 80 KB of LDS per workgroup; it is not built.
 template <int OP, int TERMS>
 int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
-  constexpr bool BIG = TERMS == 1;
+  constexpr bool BIG = TERMS != 3;
   if (tile == 0 || (!BIG && tile == 1)) {
     static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
     static const double eff[4] = {1.00, 0.70, 0.85, 0.85};
@@ -538,7 +551,7 @@ int run_glds_bf16(const IckGemm* d, int terms, const P& p, int nz, hipStream_t s
 }
 
 extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
-  ICK_REQUIRE(terms == 1 || terms == 3, "ick_gemm_bf16: terms must be 1 (bf16) or 3 (split bf16), got %d", terms);
+  ICK_REQUIRE(terms >= 1 && terms <= 3, "ick_gemm_bf16: terms must be 1 (bf16), 2 (fp16) or 3 (split bf16), got %d", terms);
   P p; int nz = 1;
   if (int rc = prepare(d, BK, p, nz, "ick_gemm_bf16")) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -586,5 +599,5 @@ extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
     return run_glds_bf16(&dd, terms, p, nz, st);
   }
   IckGemm dd = *d; dd.tile &= 15;      // the register-staged family has the four plain tile shapes only
-  return terms == 3 ? run<3>(&dd, p, nz, st) : run<1>(&dd, p, nz, st);
+  return terms == 3 ? run<3>(&dd, p, nz, st) : terms == 2 ? run<2>(&dd, p, nz, st) : run<1>(&dd, p, nz, st);
 }

@@ -21,6 +21,16 @@ using namespace ickg;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// TERMS: 1 = bf16, 3 = split bf16, 2 = fp16 (v_mfma_f32_32x32x16_f16: the reference's autocast dtype, train_student_kd.py:271;
+// 10 mantissa bits instead of bf16's 7, but a 5-bit exponent: the caller runs it under the device-side GradScaler)
+template <int TERMS> struct Half16 { using x8 = bf16x8; };
+template <> struct Half16<2> { using x8 = f16x8; };
+template <int TERMS, typename V>
+__device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
+  if constexpr (TERMS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 constexpr int BK = 32;
 constexpr int NT = 256;
@@ -303,26 +313,27 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
 #pragma unroll
         for (int t = 0; t < TN; ++t) bv[nxt][t] = frag_b(Bb, s + 1, t);
       }
-      bf16x8 ah[TM], bh[TN], al[TM], bl[TN];
+      using h8 = typename Half16<TERMS>::x8;
+      h8 ah[TM], bh[TN], al[TM], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        ah[i] = __builtin_convertvector(av[cur][i], bf16x8);
-        if constexpr (TERMS == 3) al[i] = __builtin_convertvector(av[cur][i] - __builtin_convertvector(ah[i], f32x8), bf16x8);
+        ah[i] = __builtin_convertvector(av[cur][i], h8);
+        if constexpr (TERMS == 3) al[i] = __builtin_convertvector(av[cur][i] - __builtin_convertvector(ah[i], f32x8), h8);
       }
 #pragma unroll
       for (int t = 0; t < TN; ++t) {
-        bh[t] = __builtin_convertvector(bv[cur][t], bf16x8);
-        if constexpr (TERMS == 3) bl[t] = __builtin_convertvector(bv[cur][t] - __builtin_convertvector(bh[t], f32x8), bf16x8);
+        bh[t] = __builtin_convertvector(bv[cur][t], h8);
+        if constexpr (TERMS == 3) bl[t] = __builtin_convertvector(bv[cur][t] - __builtin_convertvector(bh[t], f32x8), h8);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
           if constexpr (TERMS == 3) {   // small terms first
-            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[t], acc[i][t], 0, 0, 0);
-            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[t], acc[i][t], 0, 0, 0);
+            acc[i][t] = mfma16<TERMS>(al[i], bh[t], acc[i][t]);
+            acc[i][t] = mfma16<TERMS>(ah[i], bl[t], acc[i][t]);
           }
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[t], acc[i][t], 0, 0, 0);
+          acc[i][t] = mfma16<TERMS>(ah[i], bh[t], acc[i][t]);
         }
     }
   }

@@ -70,7 +70,7 @@ _TUNED_BF16 = _load_tuned("tuned_tiles_bf16.json")     # same keys, for the bf16
 # Arithmetic of every dense contraction (Linear / attention products / convolutions): "f32" = exact fp32 MFMA (the
 # parity regime), "bf16" = bf16 MFMA with fp32 accumulation (the reference's autocast regime, train_student_kd.py:263),
 # "bf16x3" = split-bf16 (hi*hi + hi*lo + lo*hi, ~1e-5 of fp32).  Operands stay fp32 in HBM in all three.
-_PRECISIONS = {"f32": 0, "bf16": 1, "bf16x3": 3}
+_PRECISIONS = {"f32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3}     # "fp16": fp16 MFMA products (the reference's autocast dtype)
 _PREC = ["f32"]
 
 

@@ -99,10 +99,13 @@ class KDTrainer:
                  batch_size: int = 64, t_plus_1: int = 16, use_graph: bool = True, process_group=None,
                  precision: str = "f32", teacher_precision: str = "f32", overlap_teacher: bool = True,
                  accumulation_steps: int = 1, loss_scale=None, growth_interval: int = 2000, bucketed: Optional[bool] = None):
-        """precision: arithmetic of the student + projector contractions, forward and backward ("f32" exact, "bf16" =
-        the reference's autocast regime :271-285 with fp32 master weights, "bf16x3" split-bf16); the teacher runs
+        """precision: arithmetic of the student + projector contractions, forward and backward ("f32" exact; "fp16" = the
+        reference's autocast regime :271-285 — fp16 MFMA products, fp32 accumulation and master weights, GradScaler on
+        the device; "bf16" the same with bf16 products and no scaler; "bf16x3" split-bf16); the teacher runs
         outside autocast in fp32 in the reference (:265-268) -> teacher_precision defaults to "f32"."""
         self.precision, self.teacher_precision = precision, teacher_precision
+        if precision == "fp16" and loss_scale is None:
+            loss_scale = 65536.0         # torch.amp.GradScaler's init_scale: fp16's 5-bit exponent needs it (reference :239)
         # gradient accumulation (reference :229,:285,:290): `loss / accumulation_steps` per micro-batch and one
         # optimizer step per window.  Here the flat gradient buffer simply accumulates the un-divided gradients and
         # 1/accumulation_steps is folded, with 1/world, into the fused clip+AdamW pass; the all-reduce and the LR

@@ -81,7 +81,8 @@ int ick_gemm_f32(const IckGemm* desc, void* stream);
 /* The same family on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, fp32 accumulate) for the mixed-precision regime
  * the reference trains in (torch.cuda.amp.autocast + GradScaler, train_student_kd.py:263-290).  Operands, layouts and
  * epilogues are those of ick_gemm_f32 (fp32 in HBM); values are rounded to bf16 on the way into LDS.
- * terms = 1: plain bf16 products (autocast semantics); terms = 3: each operand split into hi + lo bf16 parts and
+ * terms = 1: plain bf16 products; terms = 2: fp16 products (v_mfma_f32_32x32x16_f16 — the reference's autocast dtype: 10
+ * mantissa bits, 5-bit exponent, to be run under the loss scaler); terms = 3: each operand split into hi + lo bf16 parts and
  * hi*hi + hi*lo + lo*hi accumulated (~1e-5 relative to the exact fp32 product, 3 MFMAs per k-step).
  * Convolutions whose channel count is not a multiple of 32 run on the exact-fp32 kernel. */
 int ick_gemm_bf16(const IckGemm* desc, int terms, void* stream);

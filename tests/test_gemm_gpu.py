@@ -3,7 +3,8 @@ against float64 CPU references built from torch primitives.  Tolerances, relativ
 (max |err| / max |ref|):
   f32     2e-5  exact-fp32 MFMA = fmaf chain; the reference path is fp32 too, so only summation order differs
   bf16x3  2e-4  split-bf16 (hi*hi + hi*lo + lo*hi): ~2^-16 per product
-  bf16    1.5e-2  operands rounded to 8 significant bits (the reference's autocast regime), fp32 accumulate"""
+  bf16    1.5e-2  operands rounded to 8 significant bits, fp32 accumulate
+  fp16    2e-3    operands rounded to 11 significant bits (v_mfma_f32_32x32x16_f16: the reference's autocast dtype), fp32 accumulate"""
 import math
 
 import pytest
@@ -12,7 +13,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-TOLS = {"f32": 2e-5, "bf16x3": 2e-4, "bf16": 1.5e-2}
+TOLS = {"f32": 2e-5, "bf16x3": 2e-4, "bf16": 1.5e-2, "fp16": 2e-3}
 TOL = 2e-5          # rebound per test by the `ops` fixture
 
 
@@ -22,7 +23,7 @@ def rel_err(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-@pytest.fixture(params=["f32", "bf16", "bf16x3"])
+@pytest.fixture(params=["f32", "bf16", "bf16x3", "fp16"])
 def ops(request):
     from imagecaptioner_amd import ops as o
     global TOL
