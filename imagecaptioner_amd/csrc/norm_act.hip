@@ -38,6 +38,14 @@ __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __rest
   }
 }
 
+// dst3[p][0..2] += src4[p][0..2] (the stem's weight gradient leaves its zero-padded 4-channel layout)
+__global__ void nhwc4_to_nhwc3_add_kernel(const float* __restrict__ s4, float* __restrict__ d3, long npix) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npix; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(s4)[i];
+    d3[3 * i] += v.x; d3[3 * i + 1] += v.y; d3[3 * i + 2] += v.z;
+  }
+}
+
 // images (B,3,224,224) -> rows [B*196][768], k = c*256 + py*16 + px (the flattened Conv2d(3,384,16,16) weight order)
 __global__ void patchify16_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int HW, int G) {
   const long total4 = (long)B * G * G * 192;  // float4 units
@@ -382,6 +390,92 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
+// backward of the 3x3 / stride 2 / pad 1 max-pool: dx[p] = sum over the (<= 4) windows containing p of dy[window] when p is
+// that window's FIRST maximum (torch's tie rule: the first element of the window scan, row-major).  Gather form: no atomics.
+__global__ void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                        int B, int H, int W, int C, int Ho, int Wo) {
+  const long total = (long)B * H * W * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    long r = i / C;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const long b = r / H;
+    const float v = x[i];
+    float g = 0.f;
+    // windows (oy, ox) with 2*oy-1 <= iy <= 2*oy+1
+    for (int oy = (iy >> 1); oy <= ((iy + 1) >> 1); ++oy) {
+      if (oy >= Ho) continue;
+      for (int ox = (ix >> 1); ox <= ((ix + 1) >> 1); ++ox) {
+        if (ox >= Wo) continue;
+        // is (iy, ix) the first maximum of this window?
+        bool first = true;
+        for (int dyy = 0; dyy < 3 && first; ++dyy) {
+          const int yy = oy * 2 - 1 + dyy;
+          if ((unsigned)yy >= (unsigned)H) continue;
+          for (int dxx = 0; dxx < 3; ++dxx) {
+            const int xx = ox * 2 - 1 + dxx;
+            if ((unsigned)xx >= (unsigned)W) continue;
+            const float u = x[((b * H + yy) * W + xx) * C + c];
+            const bool before = yy < iy || (yy == iy && xx < ix);
+            if (u > v || (before && u == v)) { first = false; break; }
+          }
+        }
+        if (first) g += dy[((b * Ho + oy) * Wo + ox) * C + c];
+      }
+    }
+    dx[i] = g;
+  }
+}
+
+// nn.AdaptiveAvgPool2d((Ho, Wo)) on NHWC: bin i = [floor(i*H/Ho), ceil((i+1)*H/Ho))
+__global__ void adaptive_avgpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
+                                            int Ho, int Wo) {
+  const long total = (long)B * Ho * Wo * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long r = i / C4;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho);
+    const long b = r / Ho;
+    const int y0 = (oy * H) / Ho, y1 = ((oy + 1) * H + Ho - 1) / Ho, x0 = (ox * W) / Wo, x1 = ((ox + 1) * W + Wo - 1) / Wo;
+    float4 s = make_float4(0, 0, 0, 0);
+    for (int yy = y0; yy < y1; ++yy)
+      for (int xx = x0; xx < x1; ++xx) {
+        const float4 v = reinterpret_cast<const float4*>(x)[((b * H + yy) * W + xx) * C4 + c];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    const float inv = 1.f / ((y1 - y0) * (x1 - x0));
+    reinterpret_cast<float4*>(y)[i] = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+  }
+}
+__global__ void adaptive_avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H, int W, int C4,
+                                            int Ho, int Wo) {
+  const long total = (long)B * H * W * C4;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    long r = i / C4;
+    const int ix = (int)(r % W); r /= W;
+    const int iy = (int)(r % H);
+    const long b = r / H;
+    float4 s = make_float4(0, 0, 0, 0);
+    int oy_lo = (int)(((long)iy * Ho) / H) - 1; if (oy_lo < 0) oy_lo = 0;
+    int ox_lo = (int)(((long)ix * Wo) / W) - 1; if (ox_lo < 0) ox_lo = 0;
+    for (int oy = oy_lo; oy < Ho && (oy * H) / Ho <= iy; ++oy) {
+      const int y0 = (oy * H) / Ho, y1 = ((oy + 1) * H + Ho - 1) / Ho;
+      if (iy < y0 || iy >= y1) continue;
+      for (int ox = ox_lo; ox < Wo && (ox * W) / Wo <= ix; ++ox) {
+        const int x0 = (ox * W) / Wo, x1 = ((ox + 1) * W + Wo - 1) / Wo;
+        if (ix < x0 || ix >= x1) continue;
+        const float inv = 1.f / ((y1 - y0) * (x1 - x0));
+        const float4 v = reinterpret_cast<const float4*>(dy)[((b * Ho + oy) * Wo + ox) * C4 + c];
+        s.x += v.x * inv; s.y += v.y * inv; s.z += v.z * inv; s.w += v.w * inv;
+      }
+    }
+    reinterpret_cast<float4*>(dx)[i] = s;
+  }
+}
+
 // ------------------------------------------------------------------ LayerNorm (one wave per row)
 __global__ void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
                                      const float* __restrict__ b, float* __restrict__ y, float* __restrict__ mean_out,
@@ -593,6 +687,12 @@ int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stre
   return ick::launch_status("nchw3_to_nhwc4");
 }
 
+int ick_nhwc4_to_nhwc3_add(const float* src4, float* dst3, int64_t npix, void* stream) {
+  ICK_REQUIRE(src4 && dst3 && npix > 0, "ick_nhwc4_to_nhwc3_add: bad arguments");
+  ICK_LAUNCH(nhwc4_to_nhwc3_add_kernel, dim3(grid_for(npix)), dim3(NT), 0, ST, src4, dst3, (long)npix);
+  return ick::launch_status("nhwc4_to_nhwc3_add");
+}
+
 int ick_patchify16(const float* x, float* y, int B, int HW, void* stream) {
   ICK_REQUIRE(x && y && B > 0 && HW % 16 == 0, "ick_patchify16: bad arguments");
   const int G = HW / 16;
@@ -708,6 +808,25 @@ int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void*
   ICK_LAUNCH(maxpool3x3s2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(NT), 0, ST, x, y, B, H, W, C / 4,
                      Ho, Wo);
   return ick::launch_status("maxpool3x3s2");
+}
+
+int ick_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+  ICK_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "ick_maxpool3x3s2_bwd: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  ICK_LAUNCH(maxpool3x3s2_bwd_kernel, dim3(grid_for((long)B * H * W * C)), dim3(NT), 0, ST, x, dy, dx, B, H, W, C, Ho, Wo);
+  return ick::launch_status("maxpool3x3s2_bwd");
+}
+
+int ick_adaptive_avgpool_fwd(const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo, void* stream) {
+  ICK_REQUIRE(x && y && C % 4 == 0 && Ho > 0 && Wo > 0 && H >= Ho && W >= Wo, "ick_adaptive_avgpool_fwd: bad arguments");
+  ICK_LAUNCH(adaptive_avgpool_fwd_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(NT), 0, ST, x, y, B, H, W, C / 4, Ho, Wo);
+  return ick::launch_status("adaptive_avgpool_fwd");
+}
+
+int ick_adaptive_avgpool_bwd(const float* dy, float* dx, int B, int H, int W, int C, int Ho, int Wo, void* stream) {
+  ICK_REQUIRE(dy && dx && C % 4 == 0 && Ho > 0 && Wo > 0 && H >= Ho && W >= Wo, "ick_adaptive_avgpool_bwd: bad arguments");
+  ICK_LAUNCH(adaptive_avgpool_bwd_kernel, dim3(grid_for((long)B * H * W * (C / 4))), dim3(NT), 0, ST, dy, dx, B, H, W, C / 4, Ho, Wo);
+  return ick::launch_status("adaptive_avgpool_bwd");
 }
 
 int ick_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows,

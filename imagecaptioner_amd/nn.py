@@ -402,17 +402,17 @@ class ResNetTrunkFn(Function):
         images = _c(images)
         x4 = ops.nchw3_to_nhwc4(images)
         stem: Conv2d = resnet[0]
-        if any(p.requires_grad for p in list(stem.parameters()) + list(resnet[1].parameters())):
-            raise NotImplementedError("the 7x7 stem is frozen in the reference (student_model.py:23-27); its backward is not built")
+        # the reference freezes the stem only under fine_tune=True (student_model.py:23-30); CNNEncoder(fine_tune=False) trains it
+        stem_trainable = any(p.requires_grad for p in list(stem.parameters()) + list(resnet[1].parameters()))
         w4 = ops.nchw3_to_nhwc4(_c(stem.weight.detach()))          # (64,3,7,7) -> (64,7,7,4), zero 4th channel
         blocks: List[Bottleneck] = [b for li in (4, 5, 6, 7) for b in resnet[li]]
         arena = counters = None
         if train:
             # up to 8 accumulator copies per BatchNorm (ops.stat_copies)
             arena, counters = _Arena(2 * (64 + _bn_channels(blocks)) * 8, torch.float64, images.device), []
-        y, _, _, _ = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters)
-        y = ops.maxpool3x3s2(y)
-        first = next((i for i, b in enumerate(blocks) if _block_trainable(b)), len(blocks))
+        ys, raw_s, mean_s, inv_s = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters)
+        y = ops.maxpool3x3s2(ys)
+        first = 0 if stem_trainable else next((i for i, b in enumerate(blocks) if _block_trainable(b)), len(blocks))
         want_bwd = any(ctx.needs_input_grad) and first < len(blocks)   # (forward itself always runs in no-grad mode)
         ctx.eval_mode_graph = want_bwd and not train     # eval forward under autograd (validation loops): fine until .backward()
         want_bwd = want_bwd and train
@@ -424,7 +424,13 @@ class ResNetTrunkFn(Function):
         if counters:
             torch._foreach_add_(counters, 1)       # all num_batches_tracked counters in one launch (bookkeeping)
         ctx.blocks, ctx.first, ctx.recs = blocks, first, recs
+        ctx.stem = dict(x4=x4, ys=ys, raw=raw_s, mean=mean_s, inv=inv_s, conv=stem, bn=resnet[1]) if (want_bwd and stem_trainable) else None
         Nb, H, W, C = y.shape
+        ctx.pool_from = None
+        if (H, W) != (7, 7):                                         # nn.AdaptiveAvgPool2d((7,7)), student_model.py:34,60: real work
+            ctx.pool_from = (H, W)                                   # only for inputs other than 224 x 224
+            y = ops.adaptive_avgpool_fwd(y, 7, 7)
+            H = W = 7
         return y.view(Nb, H * W, C)                                  # (B,49,2048): NHWC is already "permute(0,2,1)"
 
     @staticmethod
@@ -434,8 +440,12 @@ class ResNetTrunkFn(Function):
             raise NotImplementedError("backward through eval-mode BatchNorm is not needed by the KD step")
         if not recs:
             return (None,) * len(ctx.needs_input_grad)
-        d = _c(dy).view(recs[-1]["out"].shape)
-        state = dict(blocks=blocks, first=first, recs=recs, d=d, next=len(blocks) - 1,
+        if ctx.pool_from is not None:
+            Nb, C = recs[-1]["out"].shape[0], recs[-1]["out"].shape[3]
+            d = ops.adaptive_avgpool_bwd(_c(dy).view(Nb, 7, 7, C), *ctx.pool_from)
+        else:
+            d = _c(dy).view(recs[-1]["out"].shape)
+        state = dict(blocks=blocks, first=first, recs=recs, d=d, next=len(blocks) - 1, stem=ctx.stem,
                      sums=_Arena(2 * ops.BN_BWD_COPIES * _bn_channels(blocks[first:]), torch.float64, d.device))
         if _TRUNK_DEFER["on"]:
             # data-parallel step: the trainer runs the trunk's backward itself, stage by stage, so that the gradient
@@ -454,10 +464,20 @@ def trunk_backward_stage(state: dict, stop: int) -> None:
     accumulate into .grad, the running dL/dx is carried in the state for the next stage."""
     blocks, first, recs = state["blocks"], state["first"], state["recs"]
     stop = max(stop, first)
+    stem = state.get("stem")
     for i in range(state["next"], stop - 1, -1):
-        state["d"] = bottleneck_backward(blocks[i], recs[i - first], state["d"], i > first, state["sums"])
+        state["d"] = bottleneck_backward(blocks[i], recs[i - first], state["d"], i > first or stem is not None, state["sums"])
         recs[i - first] = None                                       # free this block's activations
     state["next"] = stop - 1
+    if stem is not None and state["next"] < first:                   # CNNEncoder(fine_tune=False): max-pool, bn1, conv1 adjoints
+        bn, conv = stem["bn"], stem["conv"]
+        d = ops.maxpool3x3s2_bwd(stem["ys"], state["d"])
+        dx, _ = ops.bn_bwd(d, stem["ys"], stem["raw"], stem["mean"], stem["inv"], bn.weight, grad_buf(bn.weight), grad_buf(bn.bias),
+                           False, True)
+        dw4 = ops.zeros(conv.weight.shape[0], conv.k, conv.k, 4, device=dx.device)
+        ops.conv_wgrad(dx, stem["x4"], dw4, conv.stride, conv.padding)
+        ops.nhwc4_to_nhwc3_add(dw4, conv.packed_grad())
+        state["stem"] = None
 
 
 class deferred_trunk_backward:

@@ -461,6 +461,35 @@ def maxpool3x3s2(x):
     return y
 
 
+def nhwc4_to_nhwc3_add(src4: torch.Tensor, dst3: torch.Tensor) -> None:
+    """dst3[..., c] += src4[..., c] for c < 3 (gradient of the RGB stem weight out of its zero-padded 4-channel form);
+    dst3 is the physical [Cout][R][S][3] view of a channels_last (Cout,3,R,S) tensor."""
+    n = src4.numel() // 4
+    assert dst3.numel() == 3 * n and src4.is_contiguous()
+    check(_lib.lib().ick_nhwc4_to_nhwc3_add(src4.data_ptr(), dst3.data_ptr(), n, _st()), "ick_nhwc4_to_nhwc3_add")
+
+
+def maxpool3x3s2_bwd(x, dy):
+    Nb, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    check(_lib.lib().ick_maxpool3x3s2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), Nb, H, W, C, _st()), "ick_maxpool3x3s2_bwd")
+    return dx
+
+
+def adaptive_avgpool_fwd(x, Ho: int, Wo: int):
+    Nb, H, W, C = x.shape
+    y = empty(Nb, Ho, Wo, C, device=x.device)
+    check(_lib.lib().ick_adaptive_avgpool_fwd(x.data_ptr(), y.data_ptr(), Nb, H, W, C, Ho, Wo, _st()), "ick_adaptive_avgpool_fwd")
+    return y
+
+
+def adaptive_avgpool_bwd(dy, H: int, W: int):
+    Nb, Ho, Wo, C = dy.shape
+    dx = empty(Nb, H, W, C, device=dy.device)
+    check(_lib.lib().ick_adaptive_avgpool_bwd(dy.data_ptr(), dx.data_ptr(), Nb, H, W, C, Ho, Wo, _st()), "ick_adaptive_avgpool_bwd")
+    return dx
+
+
 def nchw3_to_nhwc4(images):
     B, C, H, W = images.shape
     assert C == 3 and images.is_contiguous()

@@ -53,9 +53,9 @@ class CNNEncoder(nn.Module):
         self.embed_size = embed_size
 
     def forward(self, images):
-        if images.shape[-2:] != (224, 224):
-            raise NotImplementedError("the HIP trunk is built for 224x224 inputs (AdaptiveAvgPool2d(7,7) is then the identity)")
-        f = hnn.resnet_trunk(images, self.resnet, self.training)     # (B,49,2048), NHWC rows
+        if images.shape[-2] < 193 or images.shape[-1] < 193:
+            raise ValueError("inputs smaller than 193x193 leave the trunk with fewer than 7x7 positions to pool into (7,7)")
+        f = hnn.resnet_trunk(images, self.resnet, self.training)     # (B,49,2048), NHWC rows (adaptive-pooled if not 224x224)
         return self.projection(f)                                    # (B,49,E)
 
 
@@ -146,9 +146,15 @@ class DecoderFn(Function):
     """Teacher-forced decode of all T steps + hand-written BPTT (see module docstring)."""
 
     @staticmethod
-    def forward(ctx, feats, captions, dec: "LSTMDecoder", train: bool, *params):
+    def forward(ctx, feats, captions, dec: "LSTMDecoder", train: bool, h0, c0, *params):
+        """h0 / c0: optional caller-supplied initial state (layers, B, H) — LSTMDecoder.forward(hidden=...), reference :205,220;
+        they enter as constants (no gradient flows back into them)."""
         feats = hnn._c(feats)
         captions = hnn._c(captions)
+        if h0 is not None:
+            h0, c0 = hnn._c(h0.detach()), hnn._c(c0.detach())
+        hp = lambda l, t: Hall[l, t - 1] if t > 0 else (h0[l] if h0 is not None else None)
+        cp = lambda l, t: Call[l, t - 1] if t > 0 else (c0[l] if c0 is not None else None)
         T, B = captions.shape
         _, P, E = feats.shape
         H, NL, V = dec.hidden_size, dec.num_layers, dec.vocab_size
@@ -178,12 +184,12 @@ class DecoderFn(Function):
             hW = ops.empty(T, B, E, device=dev)
             X = ops.empty(T, B, E, device=dev)
             for t in range(T):
-                ops.dec_attn_x_fwd(Hall[NL - 1, t - 1] if t > 0 else None, Wa, Uf, feats, Wc, Xe[t], hW[t], attw[t], ctxs[t], X[t])
+                ops.dec_attn_x_fwd(hp(NL - 1, t), Wa, Uf, feats, Wc, Xe[t], hW[t], attw[t], ctxs[t], X[t])
                 inp = X[t]
                 for l in range(NL):
                     wi, wh, bi, bh = dec.lstm.layer(l)
                     hd = Hd[l, t] if (p_lstm > 0 and l < NL - 1) else None
-                    ops.lstm_layer_fwd(inp, Hall[l, t - 1] if t > 0 else None, wi, wh, bi, bh, Call[l, t - 1] if t > 0 else None,
+                    ops.lstm_layer_fwd(inp, hp(l, t), wi, wh, bi, bh, cp(l, t),
                                        Gates[l, t] if keep else None, Call[l, t], Hall[l, t], hd, p_lstm,
                                        seeds[l][t] if hd is not None else 0)
                     inp = hd if hd is not None else Hall[l, t]
@@ -195,8 +201,8 @@ class DecoderFn(Function):
             zero_h = ops.zeros(B, H, device=dev)
             Gall = ops.zeros(T, NL, B, 4 * H, device=dev)
             for t in range(T):
-                h_top = Hall[NL - 1, t - 1] if t > 0 else zero_h
-                ops.gemm_nt(h_top, Wa.data_ptr(), E, H, H + E, hW[t], zeroed=True)
+                h_top = hp(NL - 1, t)
+                ops.gemm_nt(h_top if h_top is not None else zero_h, Wa.data_ptr(), E, H, H + E, hW[t], zeroed=True)
                 ops.attn_step_fwd(Uf, hW[t], feats, attw[t], ctxs[t])
                 ops.gemm_nt(ctxs[t], Wc.data_ptr() + E * fs, E, E, 2 * E, X[t], residual=Xe[t], zeroed=True)
                 inp = X[t]
@@ -204,10 +210,9 @@ class DecoderFn(Function):
                     wi, wh, bi, bh = dec.lstm.layer(l)
                     G = Gall[t, l]
                     ops.gemm_nt(inp, wi.data_ptr(), 4 * H, wi.shape[1], wi.shape[1], G, zeroed=True)
-                    if t > 0:
-                        ops.gemm_nt(Hall[l, t - 1], wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
-                    ops.lstm_cell_fwd(G, bi, bh, Call[l, t - 1] if t > 0 else None, Gates[l, t] if keep else None, Call[l, t],
-                                      Hall[l, t])
+                    if hp(l, t) is not None:
+                        ops.gemm_nt(hp(l, t), wh.data_ptr(), 4 * H, H, H, G, accumulate=True)
+                    ops.lstm_cell_fwd(G, bi, bh, cp(l, t), Gates[l, t] if keep else None, Call[l, t], Hall[l, t])
                     inp = Hall[l, t]
                     if p_lstm > 0 and l < NL - 1:
                         ops.dropout(Hall[l, t], Hd[l, t], p_lstm, seeds[l][t])
@@ -224,7 +229,7 @@ class DecoderFn(Function):
             ctx.dec, ctx.dims = dec, (T, B, P, E, H, NL, V)
             ctx.saved = dict(feats=feats, captions=captions, Uf=Uf, emb=emb, Hall=Hall, Call=Call, Gates=Gates, Hd=Hd, hW=hW,
                              attw=attw, ctxs=ctxs, X=X, Z=Z, Zd=Zd, seed_z=seed_z, p_drop=p_drop, p_lstm=p_lstm, seeds=seeds,
-                             fused=fused)
+                             fused=fused, h0=h0, c0=c0)
         hs_out = Hs
         ctx.mark_non_differentiable(attw)
         return logits, hs_out, attw
@@ -236,6 +241,7 @@ class DecoderFn(Function):
         s = ctx.saved
         dev = s["feats"].device
         fs = 4
+        h0, c0 = s["h0"], s["c0"]
         Wa, Wc = dec.attention.weight, dec.attention_combine.weight
         W1, W2 = dec.output_projection[0].weight, dec.output_projection[3].weight
         b1, b2 = dec.output_projection[0].bias, dec.output_projection[3].bias
@@ -283,7 +289,7 @@ class DecoderFn(Function):
 
             def cell(l, t, first):
                 return dict(carry_h=None if first else carry_h[l], carry_c=carry_c[l], gates=Gates[l, t], c=Call[l, t],
-                            c_prev=Call[l, t - 1] if t > 0 else None, dG=DG[l, t], first=first)
+                            c_prev=Call[l, t - 1] if t > 0 else (c0[l] if c0 is not None else None), dG=DG[l, t], first=first)
 
             ops.dec_attn_x_bwd(None, Wc, None, s["Uf"], None, s["feats"], dUf, dfeats, None, Wa, dHs[T - 1], cell(top, T - 1, True))
             for t in range(T - 1, -1, -1):
@@ -304,7 +310,8 @@ class DecoderFn(Function):
                     wi, wh, _, _ = dec.lstm.layer(l)
                     dh_a = dHs[t] if l == NL - 1 else d_inp[t, l + 1]
                     ops.lstm_cell_bwd(dh_a, carry[t, l] if t < T - 1 else None, carry_c[l] if t < T - 1 else None, Gates[l, t],
-                                      Call[l, t], Call[l, t - 1] if t > 0 else None, DG[l, t], carry_c[l])
+                                      Call[l, t], Call[l, t - 1] if t > 0 else (c0[l] if c0 is not None else None), DG[l, t],
+                                      carry_c[l])
                     if t > 0:
                         ops.gemm_nn(DG[l, t], wh.data_ptr(), 4 * H, H, H, carry[t - 1, l], zeroed=True)
                     if l > 0:
@@ -330,6 +337,8 @@ class DecoderFn(Function):
                                 4 * H, H, H)
             else:
                 gb(wh)
+            if h0 is not None:                                  # the caller's initial state feeds step 0's recurrent product
+                ops.gemm_tn_acc(DG[l, 0], h0[l], gb(wh).data_ptr(), 4 * H, H, H)
             ops.colsum_into(DG[l].view(T * B, 4 * H), gb(bi))
             ops.colsum_into(DG[l].view(T * B, 4 * H), gb(bh))
         dX2 = dX.view(T * B, E)
@@ -347,11 +356,13 @@ class DecoderFn(Function):
             gWa = gb(Wa)
             if T > 1:
                 ops.gemm_tn_acc(dhW[1:].reshape((T - 1) * B, E), Hs[:-1].reshape((T - 1) * B, H), gWa.data_ptr(), E, H, H + E)
+            if h0 is not None:
+                ops.gemm_tn_acc(dhW[0], h0[NL - 1], gWa.data_ptr(), E, H, H + E)
             ops.gemm_tn_acc(dUf2, feats2, gWa.data_ptr() + H * fs, E, E, H + E)
             ops.colsum_into(dUf2, gb(dec.attention.bias))
         ops.gemm_nn(dUf2, Wa.data_ptr() + H * fs, E, E, H + E, dfeats.view(B * P, E), accumulate=True)
         ctx.saved = None
-        return (dfeats, None, None, None) + (None,) * (len(ctx.needs_input_grad) - 4)
+        return (dfeats,) + (None,) * (len(ctx.needs_input_grad) - 1)
 
 
 class LSTMDecoder(nn.Module):
@@ -389,10 +400,10 @@ class LSTMDecoder(nn.Module):
         return ctx, w
 
     def forward(self, image_features, captions, hidden=None):
-        if hidden is not None:
-            raise NotImplementedError("a caller-supplied initial state is not used anywhere in the reference's hot path")
+        """hidden: optional (h0, c0), each (num_layers, B, H), as in the reference (:205,:220); None = zero state."""
         params = [p for p in self.parameters() if p.requires_grad]
-        logits, hs, attw = DecoderFn.apply(image_features, captions, self, self.training, *params)
+        h0, c0 = hidden if hidden is not None else (None, None)
+        logits, hs, attw = DecoderFn.apply(image_features, captions, self, self.training, h0, c0, *params)
         return logits, list(hs.unbind(0)), list(attw.unbind(0))
 
     @torch.no_grad()

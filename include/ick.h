@@ -99,6 +99,7 @@ int ick_attention_fwd_d64(const float* q, int64_t qld, int64_t qbs, const float*
 /* ------------------------------------------------------------------ layout transforms
  * images arrive as the reference hands them over: (B,3,224,224) fp32 NCHW (train_student_kd.py:259). */
 int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stream);      /* -> (B,H,W,4), 4th channel 0 */
+int ick_nhwc4_to_nhwc3_add(const float* src4, float* dst3, int64_t npix, void* stream);      /* dst3[p][c] += src4[p][c], c < 3 */
 int ick_patchify16(const float* x, float* y, int B, int HW, void* stream);                /* -> [B*(HW/16)^2][768], k=(c,py,px): timm PatchEmbed as a GEMM */
 int ick_conv_weight_dgrad_layout(const float* w, float* wt, int Cout, int R, int S, int Cin, void* stream); /* wt[ci][R-1-r][S-1-s][co] = w[co][r][s][ci]: with it the stride-1 data gradient of a convolution (autograd of student_model.py:57 through layer3/layer4) is a forward convolution over dY with pad R-1-pad, both GEMM operands k-contiguous */
 int ick_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int Ntok, int D, void* stream); /* cls token + pos_embed (timm forward_features) */
@@ -134,6 +135,9 @@ int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int 
                        float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                        float* y, float* save_mean, float* save_invstd, int64_t M, int C, int relu, void* stream); /* bn_finalize + scale_shift_act in one pass */
 int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream); /* nn.MaxPool2d(3,2,1), NHWC */
+int ick_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream); /* its adjoint (first maximum of a window takes the gradient): only CNNEncoder(fine_tune=False) trains below layer3 */
+int ick_adaptive_avgpool_fwd(const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo, void* stream); /* nn.AdaptiveAvgPool2d((7,7)) (student_model.py:34,60) on NHWC: the identity at 224x224 inputs, real pooling otherwise */
+int ick_adaptive_avgpool_bwd(const float* dy, float* dx, int B, int H, int W, int C, int Ho, int Wo, void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm / softmax / small utilities
  * nn.LayerNorm (student_model.py:41,99-100; teacher_model.py:70; timm blocks eps=1e-6; distillation_utils.py:221) */

@@ -151,11 +151,12 @@ def output_projection(sd: SD, h_top: torch.Tensor, train: bool = False, p_drop: 
 
 
 def lstm_decoder(sd: SD, feats: torch.Tensor, captions: torch.Tensor, layers: int, hidden: int,
-                 train: bool = False, p_drop: float = 0.0, p: str = "decoder"):
-    """LSTMDecoder.forward (teacher forcing), /root/reference/src/student_model.py:205-256."""
+                 train: bool = False, p_drop: float = 0.0, p: str = "decoder", init=None):
+    """LSTMDecoder.forward (teacher forcing), /root/reference/src/student_model.py:205-256.  init = (h0, c0), each
+    (layers, B, H): the caller-supplied initial state of :205,:220 (None = init_hidden's zeros)."""
     T, B = captions.shape
-    h = [feats.new_zeros(B, hidden) for _ in range(layers)]
-    c = [feats.new_zeros(B, hidden) for _ in range(layers)]
+    h = [feats.new_zeros(B, hidden) for _ in range(layers)] if init is None else list(init[0].unbind(0))
+    c = [feats.new_zeros(B, hidden) for _ in range(layers)] if init is None else list(init[1].unbind(0))
     emb = F.embedding(captions, sd[p + ".embedding.weight"])        # (T,B,E)
     outs, hids, attw = [], [], []
     for t in range(T):
