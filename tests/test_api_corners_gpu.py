@@ -48,7 +48,7 @@ def test_decoder_with_caller_supplied_initial_state(E, H, NL):
     z = torch.zeros(NL, B, H, device="cuda")
     a = dec(feats.cuda(), caps.cuda(), hidden=(z, z))[0]
     b = dec(feats.cuda(), caps.cuda())[0]
-    assert torch.equal(a, b)
+    assert rel(a, b) < 1e-6      # (not bit-equal: with an explicit state the zero recurrent half takes part in the K split)
 
 
 def test_adaptive_avgpool_kernels_vs_torch():
