@@ -157,7 +157,10 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
       const float4 r = reinterpret_cast<const float4*>(res)[i];
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
-    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    if (relu) {      // 1 = ReLU, 2 = ReLU6 (MobileNetV2)
+      const float hi = relu == 2 ? 6.f : INFINITY;
+      o.x = fminf(fmaxf(o.x, 0.f), hi); o.y = fminf(fmaxf(o.y, 0.f), hi); o.z = fminf(fmaxf(o.z, 0.f), hi); o.w = fminf(fmaxf(o.w, 0.f), hi);
+    }
     reinterpret_cast<float4*>(y)[i] = o;
   }
 }
@@ -242,17 +245,19 @@ struct d4 { double x, y, z, w; };
 __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                      const float* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ inv, double* __restrict__ sum_g,
-                                     double* __restrict__ sum_gx, int copies, long stride, long M, int C) {
+                                     double* __restrict__ sum_gx, int copies, long stride, long M, int C, float hi) {
   const int C4 = C >> 2;
   const int lanes = C4 < NT ? C4 : NT;     // threads along channels
-  const int rows = NT / lanes;             // threads along rows
+  const int rows = NT / lanes;             // threads along rows (threads beyond rows * lanes idle: C/4 need not divide 256)
   const int tc = threadIdx.x % lanes, tr = threadIdx.x / lanes;
   __shared__ d4 sh_g[NT], sh_x[NT];
-  for (int c4 = blockIdx.x * lanes + tc; c4 < C4; c4 += gridDim.x * lanes) {
-    const float4 muf = reinterpret_cast<const float4*>(mean)[c4];
+  for (int cbase = blockIdx.x * lanes; cbase < C4; cbase += gridDim.x * lanes) {     // block-uniform trip count (barriers inside)
+    const int c4 = cbase + tc;
+    const bool cok = c4 < C4;
+    const float4 muf = cok ? reinterpret_cast<const float4*>(mean)[c4] : make_float4(0, 0, 0, 0);
     const d4 mu = {muf.x, muf.y, muf.z, muf.w};
     d4 dg = {0, 0, 0, 0}, dx = {0, 0, 0, 0};
-    if (tr < rows) {
+    if (tr < rows && cok) {
       // 4 rows per trip: 12 independent 16-byte loads in flight per thread (one row per trip left the kernel
       // latency-bound at ~3.6 TB/s with 1.5 workgroups per CU)
       const long step = (long)gridDim.y * rows;
@@ -269,8 +274,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if (y) {
-            g[u].x = yy[u].x > 0.f ? g[u].x : 0.f; g[u].y = yy[u].y > 0.f ? g[u].y : 0.f;
-            g[u].z = yy[u].z > 0.f ? g[u].z : 0.f; g[u].w = yy[u].w > 0.f ? g[u].w : 0.f;
+            g[u].x = (yy[u].x > 0.f && yy[u].x < hi) ? g[u].x : 0.f; g[u].y = (yy[u].y > 0.f && yy[u].y < hi) ? g[u].y : 0.f;
+            g[u].z = (yy[u].z > 0.f && yy[u].z < hi) ? g[u].z : 0.f; g[u].w = (yy[u].w > 0.f && yy[u].w < hi) ? g[u].w : 0.f;
           }
           dg.x += g[u].x; dg.y += g[u].y; dg.z += g[u].z; dg.w += g[u].w;
           dx.x = fma((double)g[u].x, (double)xv[u].x - mu.x, dx.x); dx.y = fma((double)g[u].y, (double)xv[u].y - mu.y, dx.y);
@@ -282,8 +287,8 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
         float4 g = reinterpret_cast<const float4*>(dy)[o];
         if (y) {
           const float4 yy = reinterpret_cast<const float4*>(y)[o];
-          g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-          g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+          g.x = (yy.x > 0.f && yy.x < hi) ? g.x : 0.f; g.y = (yy.y > 0.f && yy.y < hi) ? g.y : 0.f;
+          g.z = (yy.z > 0.f && yy.z < hi) ? g.z : 0.f; g.w = (yy.w > 0.f && yy.w < hi) ? g.w : 0.f;
         }
         const float4 xv = reinterpret_cast<const float4*>(x)[o];
         dg.x += g.x; dg.y += g.y; dg.z += g.z; dg.w += g.w;
@@ -293,7 +298,7 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
     }
     sh_g[threadIdx.x] = dg; sh_x[threadIdx.x] = dx;
     __syncthreads();
-    if (tr == 0) {
+    if (tr == 0 && cok) {
       for (int r = 1; r < rows; ++r) {
         const d4 a = sh_g[r * lanes + tc], b = sh_x[r * lanes + tc];
         dg.x += a.x; dg.y += a.y; dg.z += a.z; dg.w += a.w;
@@ -329,12 +334,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ inv, const float* __restrict__ gamma,
                                     const float* __restrict__ coef, float* __restrict__ dx, float* __restrict__ gout,
-                                    long total4, int C4, int use_batch_stats) {
-  // the grid stride is a multiple of C4 (launcher), so a thread's 4 channels never change: per-channel terms once
+                                    long total4, int C4, int use_batch_stats, int hoist, float hi) {
+  // hoist: the grid stride is a multiple of C4 (launcher), so a thread's 4 channels never change: per-channel terms once.
+  // Otherwise (C/4 neither divides nor is a multiple of 256: MobileNetV2's 96, 144, 576 ...) they are re-read per element.
   const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
-  const int c = (int)(i0 % C4);
-  const float4 ga = reinterpret_cast<const float4*>(gamma)[c];
-  const float4 iv = reinterpret_cast<const float4*>(inv)[c];
+  int c = (int)(i0 % C4);
+  float4 ga = reinterpret_cast<const float4*>(gamma)[c];
+  float4 iv = reinterpret_cast<const float4*>(inv)[c];
   float4 mu = make_float4(0, 0, 0, 0), mg = mu, mx = mu;
   if (use_batch_stats) {
     mu = reinterpret_cast<const float4*>(mean)[c];
@@ -342,11 +348,21 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     mx = reinterpret_cast<const float4*>(coef)[C4 + c];
   }
   for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
+    if (!hoist) {
+      c = (int)(i % C4);
+      ga = reinterpret_cast<const float4*>(gamma)[c];
+      iv = reinterpret_cast<const float4*>(inv)[c];
+      if (use_batch_stats) {
+        mu = reinterpret_cast<const float4*>(mean)[c];
+        mg = reinterpret_cast<const float4*>(coef)[c];
+        mx = reinterpret_cast<const float4*>(coef)[C4 + c];
+      }
+    }
     float4 g = reinterpret_cast<const float4*>(dy)[i];
     if (y) {
       const float4 yy = reinterpret_cast<const float4*>(y)[i];
-      g.x = yy.x > 0.f ? g.x : 0.f; g.y = yy.y > 0.f ? g.y : 0.f;
-      g.z = yy.z > 0.f ? g.z : 0.f; g.w = yy.w > 0.f ? g.w : 0.f;
+      g.x = (yy.x > 0.f && yy.x < hi) ? g.x : 0.f; g.y = (yy.y > 0.f && yy.y < hi) ? g.y : 0.f;
+      g.z = (yy.z > 0.f && yy.z < hi) ? g.z : 0.f; g.w = (yy.w > 0.f && yy.w < hi) ? g.w : 0.f;
     }
     if (gout) reinterpret_cast<float4*>(gout)[i] = g;
     float4 o;
@@ -742,12 +758,11 @@ int ick_scale_shift_act(const float* x, const float* scale, const float* shift, 
 }
 
 int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                      double* sum_g, double* sum_gx, int copies, int64_t stride, long M, int C, void* stream) {
+                      double* sum_g, double* sum_gx, int copies, int64_t stride, long M, int C, int act, void* stream) {
   ICK_REQUIRE(copies >= 1 && (copies == 1 || stride >= C), "ick_bn_bwd_reduce: copies >= 1, stride >= C");
   ICK_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && C % 4 == 0 && M > 0, "ick_bn_bwd_reduce: bad arguments");
   const int C4 = C / 4;
   const int lanes = C4 < NT ? C4 : NT;
-  ICK_REQUIRE(NT % lanes == 0, "ick_bn_bwd_reduce: C/4=%d must divide %d or be a multiple of it", C4, NT);
   const int rows = NT / lanes;
   const int gx = (C4 + lanes - 1) / lanes;
   // Grid: ~200 workgroups in all.  Every workgroup ends with 2 x 4 x lanes fp64 atomics onto the same 2 x C addresses and
@@ -758,28 +773,29 @@ int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const flo
   const long gmax = (M + rows * 4 - 1) / (rows * 4);          // at least one 4-row trip per thread
   if (gy > gmax) gy = gmax;
   if (gy < 1) gy = 1;
-  ICK_LAUNCH(bn_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, copies, (long)stride, M, C);
+  ICK_LAUNCH(bn_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, copies, (long)stride, M, C,
+             act == 2 ? 6.f : INFINITY);
   return ick::launch_status("bn_bwd_reduce");
 }
 
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws,
-                     float* dx, float* g_out, long M, int C, int use_batch_stats, float* dgamma, float* dbeta, void* stream) {
+                     float* dx, float* g_out, long M, int C, int use_batch_stats, float* dgamma, float* dbeta, int act, void* stream) {
   if (copies < 1) copies = 1;
   ICK_REQUIRE(dy && x && mean && invstd && gamma && dx && C % 4 == 0 && M > 0, "ick_bn_bwd_apply: bad arguments");
   ICK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "ick_bn_bwd_apply: dgamma and dbeta go together");
   ICK_REQUIRE(!use_batch_stats || (sum_g && sum_gx && coef_ws), "ick_bn_bwd_apply: batch statistics need the two sums and the 2*C workspace");
   const int C4 = C / 4;
-  ICK_REQUIRE(C4 <= NT ? NT % C4 == 0 : C4 % NT == 0, "ick_bn_bwd_apply: C/4=%d must divide %d or be a multiple of it", C4, NT);
+  const int hoist = (C4 <= NT ? NT % C4 == 0 : C4 % NT == 0) ? 1 : 0;
   if (use_batch_stats)
     ICK_LAUNCH(bn_bwd_fold_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum_g, sum_gx, copies, (long)stride, 1.0 / (double)M,
                coef_ws, dgamma, dbeta, C);
   const long total4 = M * C4;
   int grid = grid_for(total4);
-  const int q = C4 > NT ? C4 / NT : 1;          // grid * NT must be a multiple of C4: a thread keeps its channels
+  const int q = (hoist && C4 > NT) ? C4 / NT : 1;          // grid * NT must be a multiple of C4: a thread keeps its channels
   grid = (grid + q - 1) / q * q;
   ICK_LAUNCH(bn_bwd_apply_kernel, dim3(grid), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, coef_ws, dx, g_out, total4, C4,
-             use_batch_stats);
+             use_batch_stats, hoist, act == 2 ? 6.f : INFINITY);
   return ick::launch_status("bn_bwd_apply");
 }
 

@@ -407,7 +407,8 @@ def bn_eval_coeffs(gamma, beta, rmean, rvar, eps):
     return co
 
 
-def scale_shift_act(x, scale, shift, residual, relu: bool, out=None):
+def scale_shift_act(x, scale, shift, residual, relu, out=None):
+    """relu: False / True, or the activation code 2 = ReLU6."""
     C = x.shape[-1]
     y = out if out is not None else torch.empty_like(x)
     check(_lib.lib().ick_scale_shift_act(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), _ptr(residual), y.data_ptr(),
@@ -418,7 +419,7 @@ def scale_shift_act(x, scale, shift, residual, relu: bool, out=None):
 BN_BWD_COPIES = int(__import__("os").environ.get("ICK_BN_BWD_COPIES", "8"))      # accumulator rows of the BatchNorm-backward sums (spreads same-address fp64 atomics)
 
 
-def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batch_stats: bool = True, sums=None):
+def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batch_stats: bool = True, sums=None, act: int = 1):
     """Backward through [relu](bn(x)[+res]).  dy: grad wrt the block output; y_mask: that output (relu mask) or None.
     Accumulates dgamma/dbeta (+=) inside the apply kernel; returns (dx, g) with g = masked dy (gradient of the
     residual branch) if want_g.  `sums`: a zeroed (2, R, C) fp64 slice of a caller-owned arena (saves one fill per BN)."""
@@ -428,14 +429,14 @@ def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batc
         sums = torch.zeros(2, BN_BWD_COPIES, C, dtype=torch.float64, device=x.device)
     R = sums.shape[1] if sums.dim() == 3 else 1
     check(_lib.lib().ick_bn_bwd_reduce(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                       sums[0].data_ptr(), sums[1].data_ptr(), R, C, M, C, _st()), "ick_bn_bwd_reduce")
+                                       sums[0].data_ptr(), sums[1].data_ptr(), R, C, M, C, act, _st()), "ick_bn_bwd_reduce")
     dx = torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
     coef = empty(2, C, device=x.device)
     check(_lib.lib().ick_bn_bwd_apply(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                       gamma.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), R, C, coef.data_ptr(),
                                       dx.data_ptr(), _ptr(g),
-                                      M, C, int(batch_stats), _ptr(dgamma), _ptr(dbeta), _st()), "ick_bn_bwd_apply")
+                                      M, C, int(batch_stats), _ptr(dgamma), _ptr(dbeta), act, _st()), "ick_bn_bwd_apply")
     return dx, g
 
 
@@ -451,6 +452,48 @@ def bn_train_apply(raw, stats, gamma, beta, rmean, rvar, momentum, eps, residual
                                         sv[0].data_ptr(), sv[1].data_ptr(), raw.numel() // C, C, int(relu), _st()),
           "ick_bn_train_apply")
     return y, sv[0], sv[1]
+
+
+def dwconv3x3_fwd(x, w, stride: int):
+    """depthwise 3x3, padding 1: x (B,H,W,C) NHWC, w (C,1,3,3) contiguous."""
+    B, H, W, C = x.shape
+    assert w.is_contiguous() and tuple(w.shape) == (C, 1, 3, 3)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    y = empty(B, Ho, Wo, C, device=x.device)
+    check(_lib.lib().ick_dwconv3x3_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), B, H, W, C, stride, _st()), "ick_dwconv3x3_fwd")
+    return y
+
+
+def dwconv3x3_dgrad(dy, w, in_hw, stride: int):
+    B, Ho, Wo, C = dy.shape
+    H, W = in_hw
+    dx = empty(B, H, W, C, device=dy.device)
+    check(_lib.lib().ick_dwconv3x3_dgrad(dy.data_ptr(), w.data_ptr(), dx.data_ptr(), B, H, W, C, stride, _st()), "ick_dwconv3x3_dgrad")
+    return dx
+
+
+def dwconv3x3_wgrad(dy, x, dw, stride: int) -> None:
+    B, H, W, C = x.shape
+    assert dw.is_contiguous()
+    check(_lib.lib().ick_dwconv3x3_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), B, H, W, C, stride, _st()), "ick_dwconv3x3_wgrad")
+
+
+def colstats(x, stats) -> None:
+    """stats (2, C) fp64 += per-channel sum / sum of squares of x (..., C)."""
+    C = x.shape[-1]
+    check(_lib.lib().ick_colstats(x.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), x.numel() // C, C, _st()), "ick_colstats")
+
+
+def dot_attn_fwd(hp, feats, emb_t, w_t, x_t) -> None:
+    B, L, E = feats.shape
+    check(_lib.lib().ick_dot_attn_fwd(hp.data_ptr(), feats.data_ptr(), emb_t.data_ptr(), w_t.data_ptr(), x_t.data_ptr(), B, L, E, _st()),
+          "ick_dot_attn_fwd")
+
+
+def dot_attn_bwd(dx_t, w_t, hp, feats, dfeats, dhp) -> None:
+    B, L, E = feats.shape
+    check(_lib.lib().ick_dot_attn_bwd(dx_t.data_ptr(), w_t.data_ptr(), hp.data_ptr(), feats.data_ptr(), dfeats.data_ptr(),
+                                      dhp.data_ptr(), B, L, E, _st()), "ick_dot_attn_bwd")
 
 
 def maxpool3x3s2(x):

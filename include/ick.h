@@ -127,10 +127,10 @@ int ick_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
 int ick_scale_shift_act(const float* x, const float* scale, const float* shift, const float* residual, float* y,
                         int64_t M, int C, int relu, void* stream);                          /* y = [relu](x*scale+shift [+ residual]) */
 int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                      double* sum_g, double* sum_gx, int copies, int64_t stride, int64_t M, int C, void* stream); /* += sum(g), sum(g*xhat) in fp64, spread over `copies` accumulator rows `stride` elements apart (row-block b adds into row b %% copies; ick_bn_bwd_apply folds them) (the reference's CPU batch_norm backward reduces in double); g = dy*(y>0) if y */
+                      double* sum_g, double* sum_gx, int copies, int64_t stride, int64_t M, int C, int act /* mask of y: 1 = ReLU (y > 0), 2 = ReLU6 (0 < y < 6) */, void* stream); /* += sum(g), sum(g*xhat) in fp64, spread over `copies` accumulator rows `stride` elements apart (row-block b adds into row b %% copies; ick_bn_bwd_apply folds them) (the reference's CPU batch_norm backward reduces in double); g = dy*(y>0) if y */
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws /* [2*C] scratch */,
-                     float* dx, float* g_out, int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, void* stream); /* dgamma/dbeta (optional) += the two sums */
+                     float* dx, float* g_out, int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, int act /* as in ick_bn_bwd_reduce */, void* stream); /* dgamma/dbeta (optional) += the two sums */
 int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                        float* y, float* save_mean, float* save_invstd, int64_t M, int C, int relu, void* stream); /* bn_finalize + scale_shift_act in one pass */
@@ -138,6 +138,20 @@ int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void*
 int ick_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream); /* its adjoint (first maximum of a window takes the gradient): only CNNEncoder(fine_tune=False) trains below layer3 */
 int ick_adaptive_avgpool_fwd(const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo, void* stream); /* nn.AdaptiveAvgPool2d((7,7)) (student_model.py:34,60) on NHWC: the identity at 224x224 inputs, real pooling otherwise */
 int ick_adaptive_avgpool_bwd(const float* dy, float* dx, int B, int H, int W, int C, int Ho, int Wo, void* stream);
+
+/* ------------------------------------------------------------------ MobileNetV2 pieces of the compact student
+ * torchvision mobilenet_v2().features as student_model_compact.py:19-22,51 runs it: depthwise 3x3 convolutions (weights in
+ * nn.Conv2d's (C,1,3,3) layout), padding 1, stride 1 or 2, NHWC fp32; ick_colstats = the BatchNorm batch statistics of their
+ * output; the 1x1 convolutions are ick_gemm_f32 NT products over pixels.  ick_scale_shift_act / ick_bn_bwd_* take act = 2 for ReLU6. */
+int ick_dwconv3x3_fwd(const float* x, const float* w, float* y, int B, int H, int W, int C, int stride, void* stream);
+int ick_dwconv3x3_dgrad(const float* dy, const float* w, float* dx, int B, int H, int W, int C, int stride, void* stream); /* (B,H,W) = INPUT geometry */
+int ick_dwconv3x3_wgrad(const float* dy, const float* x, float* dw, int B, int H, int W, int C, int stride, void* stream); /* dw += */
+int ick_colstats(const float* x, double* sum, double* sq, int64_t M, int C, void* stream);                                  /* += column sums / sums of squares (fp64) */
+/* CompactLSTMDecoder.simple_attention + the additive fusion (student_model_compact.py:114-138,175): scores_j = <hp, f_j>,
+ * w = softmax, x = emb + sum_j w_j f_j; adjoint: dfeats accumulated (+=), dhp stored */
+int ick_dot_attn_fwd(const float* hp, const float* feats, const float* emb, float* w_out, float* x_out, int B, int L, int E, void* stream);
+int ick_dot_attn_bwd(const float* dx, const float* w, const float* hp, const float* feats, float* dfeats, float* dhp, int B, int L, int E,
+                     void* stream);
 
 /* ------------------------------------------------------------------ LayerNorm / softmax / small utilities
  * nn.LayerNorm (student_model.py:41,99-100; teacher_model.py:70; timm blocks eps=1e-6; distillation_utils.py:221) */

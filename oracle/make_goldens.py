@@ -326,6 +326,48 @@ def golden_kd_step_b16(B=16):
     npz(f"kd_step_cfg3_B{B}.npz", **out)
 
 
+# ------------------------------------------------------------------ (N4) compact student
+def golden_compact():
+    """CompactCaptioningStudent (reference src/student_model_compact.py) with the MobileNetV2 stand-in: eval forward + greedy
+    caption ids, and a train-mode (batch-statistics BatchNorm, dropout 0) forward + backward with gradient slices."""
+    import student_model_compact as ref_compact
+    torch.manual_seed(0)
+    m = ref_compact.CompactCaptioningStudent(V, 256, 256, 1, use_attention_refinement=False)
+    apply_seeded_init(m, seed=7)
+    zero_dropout(m)
+    images, caps = synthetic_batch(2, V, T1, seed=4321)
+    m.eval()
+    with torch.no_grad():
+        logits, enc, hids, attw = m(images, caps[:-1])
+    vocab = _Vocab(V)
+    ids = []
+    for b in range(2):
+        words = m.caption_image(images[b], vocab, max_length=12)
+        ids.append([vocab.stoi[w] for w in words] + [-1] * (12 - len(words)))
+    out = dict(eval_logits=logits[:, :, ::10], eval_argmax=logits.argmax(-1), eval_margin=top2_margin(logits), eval_enc=enc,
+               eval_hid7=hids[7], eval_attw0=attw[0], greedy_ids=np.array(ids))
+    m.train()
+    logits, enc, hids, attw = m(images, caps[:-1])
+    g = torch.Generator().manual_seed(77)
+    dl = torch.randn(logits.shape, generator=g) * 1e-2
+    de = torch.randn(enc.shape, generator=g) * 1e-2
+    (logits * dl).sum().add((enc * de).sum()).backward()
+    sd = dict(m.named_parameters())
+    frozen = all(sd[k].grad is None for k in sd if any(k.startswith(f"encoder.backbone.{i}.") for i in range(10)))
+    out.update(train_logits=logits[:, :, ::10], train_enc=enc, frozen_none=np.array(frozen),
+               bn0_running_mean=m.encoder.backbone[0][1].running_mean, bn17_running_var=m.encoder.backbone[17].conv[3].running_var)
+    for k, sl in (("encoder.backbone.18.0.weight", np.s_[::8, ::4, 0, 0]), ("encoder.backbone.17.conv.1.0.weight", np.s_[::4, 0]),
+                  ("encoder.backbone.14.conv.0.0.weight", np.s_[::8, ::4, 0, 0]), ("encoder.backbone.10.conv.2.weight", np.s_[::2, ::8, 0, 0]),
+                  ("encoder.backbone.10.conv.1.1.weight", np.s_[:]), ("encoder.backbone.12.conv.3.bias", np.s_[:]),
+                  ("encoder.projection.0.weight", np.s_[::4, ::16]), ("decoder.attention.weight", np.s_[::4, ::4]),
+                  ("decoder.lstm.weight_hh_l0", np.s_[::16, ::4]), ("decoder.embedding.weight", np.s_[::40, ::4]),
+                  ("decoder.output_projection.weight", np.s_[::40, ::4])):
+        out["g:" + k] = sd[k].grad[sl]
+    total, trainable = ref_compact.count_parameters(m)
+    out.update(total_params=total, trainable_params=trainable, keys=np.array(sorted(m.state_dict().keys())))
+    npz("compact_student.npz", **out)
+
+
 # ------------------------------------------------------------------ (9) teacher beam search (SURVEY §8(f) N1)
 def golden_beam():
     t = build_teacher()
@@ -409,9 +451,9 @@ def golden_param_counts():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "kd_step_b16", "beam", "optloss"]
+    which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "kd_step_b16", "compact", "beam", "optloss"]
     fns = {"counts": golden_param_counts, "losses": golden_losses, "projector": golden_projector,
            "refinement": golden_refinement, "decoders": golden_decoders, "cfg1": golden_cfg1,
-           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "beam": golden_beam, "optloss": golden_optloss}
+           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "compact": golden_compact, "beam": golden_beam, "optloss": golden_optloss}
     for w in which:
         fns[w]()

@@ -169,6 +169,95 @@ def lstm_decoder(sd: SD, feats: torch.Tensor, captions: torch.Tensor, layers: in
     return torch.stack(outs, 0), hids, attw
 
 
+# ----------------------------------------------------------------------------- N4: compact student (MobileNetV2 + dot attention)
+MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+
+
+def mobilenet_v2_features(sd: SD, p: str, x: torch.Tensor, train: bool) -> torch.Tensor:
+    """torchvision mobilenet_v2().features as the reference uses it (/root/reference/src/student_model_compact.py:19-22,51):
+    19 modules, ReLU6, train-mode BatchNorm in frozen and trainable modules alike (the reference never calls .eval() on them)."""
+    def cna(q, t, stride=1, groups=1, pad=0):
+        t = F.conv2d(t, sd[q + ".0.weight"], None, stride=stride, padding=pad, groups=groups)
+        return F.relu6(_bn(sd, q + ".1", t, train))
+    x = cna(p + ".0", x, 2, 1, 1)
+    idx, cin = 1, 32
+    for t, c, n, s in MBV2_SETTINGS:
+        for i in range(n):
+            q = f"{p}.{idx}.conv"
+            stride = s if i == 0 else 1
+            y, j = x, 0
+            if t != 1:
+                y = cna(f"{q}.0", y)
+                j = 1
+            y = cna(f"{q}.{j}", y, stride, cin * t, 1)
+            y = _bn(sd, f"{q}.{j + 2}", F.conv2d(y, sd[f"{q}.{j + 1}.weight"]), train)
+            x = x + y if (stride == 1 and cin == c) else y
+            cin, idx = c, idx + 1
+    return cna(f"{p}.18", x)
+
+
+def compact_encoder(sd: SD, images: torch.Tensor, train: bool, p: str = "encoder") -> torch.Tensor:
+    """CompactCNNEncoder.forward, /root/reference/src/student_model_compact.py:41-64 (dropout p = 0 / eval)."""
+    f = mobilenet_v2_features(sd, p + ".backbone", images, train)
+    f = F.adaptive_avg_pool2d(f, (7, 7))
+    B = f.shape[0]
+    f = f.view(B, 1280, -1).permute(0, 2, 1)
+    return F.relu(_lin(sd, p + ".projection.0", f))
+
+
+def compact_decoder(sd: SD, feats: torch.Tensor, captions: torch.Tensor, hidden: int, p: str = "decoder"):
+    """CompactLSTMDecoder.forward, /root/reference/src/student_model_compact.py:114-195: dot-product attention
+    scores_j = <W_a h + b_a, f_j>, context added to the word embedding, one LSTM layer, Linear(H, V)."""
+    T, B = captions.shape
+    h = [feats.new_zeros(B, hidden)]
+    c = [feats.new_zeros(B, hidden)]
+    emb = F.embedding(captions, sd[p + ".embedding.weight"])
+    outs, hids, attw = [], [], []
+    for t in range(T):
+        hp = _lin(sd, p + ".attention", h[-1])
+        w = torch.softmax(torch.bmm(hp.unsqueeze(1), feats.transpose(1, 2)).squeeze(1), dim=1)
+        ctx = torch.bmm(w.unsqueeze(1), feats).squeeze(1)
+        h, c = lstm_step(sd, emb[t] + ctx, h, c, 1, False, 0.0, p + ".lstm")
+        outs.append(_lin(sd, p + ".output_projection", h[-1]))
+        hids.append(h[-1])
+        attw.append(w)
+    return torch.stack(outs, 0), hids, attw
+
+
+def compact_student_forward(sd: SD, images: torch.Tensor, captions: torch.Tensor, *, hidden: int, train: bool = False):
+    """CompactCaptioningStudent.forward without the optional refinement, /root/reference/src/student_model_compact.py:233-262."""
+    enc = compact_encoder(sd, images, train)
+    logits, hids, attw = compact_decoder(sd, enc, captions, hidden)
+    return logits, enc, hids, attw
+
+
+def compact_state_shapes(vocab: int, embed: int, hidden: int) -> Dict[str, Tuple[int, ...]]:
+    s: Dict[str, Tuple[int, ...]] = {}
+
+    def bn(q, c):
+        s[q + ".weight"] = (c,); s[q + ".bias"] = (c,); s[q + ".running_mean"] = (c,); s[q + ".running_var"] = (c,)
+    p = "encoder.backbone"
+    s[p + ".0.0.weight"] = (32, 3, 3, 3); bn(p + ".0.1", 32)
+    idx, cin = 1, 32
+    for t, c, n, st in MBV2_SETTINGS:
+        for i in range(n):
+            q, j, hid = f"{p}.{idx}.conv", 0, cin * t
+            if t != 1:
+                s[f"{q}.0.0.weight"] = (hid, cin, 1, 1); bn(f"{q}.0.1", hid)
+                j = 1
+            s[f"{q}.{j}.0.weight"] = (hid, 1, 3, 3); bn(f"{q}.{j}.1", hid)
+            s[f"{q}.{j + 1}.weight"] = (c, hid, 1, 1); bn(f"{q}.{j + 2}", c)
+            cin, idx = c, idx + 1
+    s[p + ".18.0.weight"] = (1280, 320, 1, 1); bn(p + ".18.1", 1280)
+    s["encoder.projection.0.weight"] = (embed, 1280); s["encoder.projection.0.bias"] = (embed,)
+    s["decoder.embedding.weight"] = (vocab, embed)
+    s["decoder.attention.weight"] = (embed, hidden); s["decoder.attention.bias"] = (embed,)
+    s["decoder.lstm.weight_ih_l0"] = (4 * hidden, embed); s["decoder.lstm.weight_hh_l0"] = (4 * hidden, hidden)
+    s["decoder.lstm.bias_ih_l0"] = (4 * hidden,); s["decoder.lstm.bias_hh_l0"] = (4 * hidden,)
+    s["decoder.output_projection.weight"] = (vocab, hidden); s["decoder.output_projection.bias"] = (vocab,)
+    return s
+
+
 # ----------------------------------------------------------------------------- A5: student
 def student_forward(sd: SD, images: torch.Tensor, captions: torch.Tensor, *, hidden: int, layers: int,
                     refine: bool, train: bool = False, p_drop: float = 0.0):

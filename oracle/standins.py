@@ -94,6 +94,55 @@ def resnet50(weights=None, **kw):
     return ResNet50()
 
 
+# ----------------------------------------------------------------------------- MobileNetV2
+# torchvision.models.mobilenet_v2 (call site /root/reference/src/student_model_compact.py:19-22: `.features`, 1280 channels).
+# Module layout and state_dict names follow torchvision: features[0] = Conv2dNormActivation(3, 32, 3, stride 2) as
+# Sequential(conv, bn, ReLU6); features[1..17] = InvertedResidual with `.conv` = Sequential([expand 1x1 CNA unless t = 1],
+# depthwise 3x3 CNA, project 1x1 Conv2d, BatchNorm2d), residual when stride 1 and cin == cout; features[18] = CNA(320, 1280, 1).
+MBV2_SETTINGS = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1))
+
+
+def _cna(cin, cout, k, stride=1, groups=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, (k - 1) // 2, groups=groups, bias=False), nn.BatchNorm2d(cout),
+                         nn.ReLU6(inplace=True))
+
+
+class InvertedResidual(nn.Module):
+    def __init__(self, cin, cout, stride, t):
+        super().__init__()
+        hid = cin * t
+        self.use_res_connect = stride == 1 and cin == cout
+        layers = []
+        if t != 1:
+            layers.append(_cna(cin, hid, 1))
+        layers += [_cna(hid, hid, 3, stride, groups=hid), nn.Conv2d(hid, cout, 1, bias=False), nn.BatchNorm2d(cout)]
+        self.conv = nn.Sequential(*layers)
+
+    def forward(self, x):
+        return x + self.conv(x) if self.use_res_connect else self.conv(x)
+
+
+class MobileNetV2(nn.Module):
+    def __init__(self, num_classes=1000):
+        super().__init__()
+        feats = [_cna(3, 32, 3, 2)]
+        cin = 32
+        for t, c, n, s in MBV2_SETTINGS:
+            for i in range(n):
+                feats.append(InvertedResidual(cin, c, s if i == 0 else 1, t))
+                cin = c
+        feats.append(_cna(cin, 1280, 1))
+        self.features = nn.Sequential(*feats)
+        self.classifier = nn.Sequential(nn.Dropout(0.2), nn.Linear(1280, num_classes))
+
+    def forward(self, x):
+        return self.classifier(self.features(x).mean((2, 3)))
+
+
+def mobilenet_v2(weights=None, **kw):
+    return MobileNetV2()
+
+
 # ----------------------------------------------------------------------------- ViT-S/16
 class _Attn(nn.Module):
     def __init__(self, dim, heads):
@@ -176,6 +225,8 @@ def install():
         tvm = types.ModuleType("torchvision.models")
         tvm.resnet50 = resnet50
         tvm.ResNet50_Weights = _Weights
+        tvm.mobilenet_v2 = mobilenet_v2
+        tvm.MobileNet_V2_Weights = _Weights
         tv.models = tvm
         sys.modules["torchvision"] = tv
         sys.modules["torchvision.models"] = tvm

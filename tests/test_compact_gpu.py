@@ -1,0 +1,126 @@
+"""SURVEY.md §8(f) row N4, second half: CompactCaptioningStudent (reference /root/reference/src/student_model_compact.py) on the
+HIP path — depthwise-convolution kernels against float64 torch, then the whole model against goldens captured from the
+reference class (tests/golden/compact_student.npz, oracle/make_goldens.py::golden_compact; MobileNetV2 stand-in in
+oracle/standins.py, torchvision being absent: parity unpinned at that boundary only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden, t
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def l2(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu().flatten(), torch.as_tensor(b).detach().double().cpu().flatten()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("B,H,W,C,stride", [(2, 14, 14, 384, 1), (3, 28, 28, 144, 2), (2, 7, 7, 960, 1), (2, 15, 13, 96, 2),
+                                              (2, 112, 112, 32, 1)])
+def test_depthwise_conv_kernels_vs_fp64(B, H, W, C, stride):
+    from imagecaptioner_amd import ops
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = torch.randn(C, 1, 3, 3, generator=g) * 0.3
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    y = F.conv2d(xr, wr, None, stride, 1, groups=C)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    yd = ops.dwconv3x3_fwd(x.cuda(), w.cuda(), stride)
+    assert rel(yd.permute(0, 3, 1, 2), y) < 1e-6
+    dyd = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    dx = ops.dwconv3x3_dgrad(dyd, w.cuda(), (H, W), stride)
+    assert rel(dx.permute(0, 3, 1, 2), xr.grad) < 1e-6
+    dw = torch.zeros(C, 1, 3, 3, device="cuda")
+    ops.dwconv3x3_wgrad(dyd, x.cuda(), dw, stride)
+    assert rel(dw, wr.grad) < 2e-5
+    stats = torch.zeros(2, C, dtype=torch.float64, device="cuda")
+    ops.colstats(yd, stats)
+    y64 = yd.double().view(-1, C)
+    assert rel(stats[0], y64.sum(0)) < 1e-9 and rel(stats[1], (y64 * y64).sum(0)) < 1e-9
+
+
+def test_relu6_batchnorm_adjoint_with_odd_channel_counts():
+    """bn_bwd_reduce / bn_bwd_apply with the ReLU6 mask (0 < y < 6) and C/4 = 36 (neither divides nor is a multiple of 256)."""
+    from imagecaptioner_amd import ops
+    M, C = 392, 144
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(M, C, generator=g) * 3 + 2
+    ga, be = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dy = torch.randn(M, C, generator=g)
+    x64, g64, b64 = x.double().requires_grad_(True), ga.double().requires_grad_(True), be.double().requires_grad_(True)
+    y64 = F.relu6(F.batch_norm(x64, None, None, g64, b64, training=True, eps=1e-5))
+    y64.backward(dy.double())
+    mean, inv = x.double().mean(0), 1.0 / torch.sqrt(x.double().var(0, unbiased=False) + 1e-5)
+    dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+    dx, _ = ops.bn_bwd(dy.cuda().view(2, 14, 14, C), y64.detach().float().cuda().view(2, 14, 14, C), x.cuda().view(2, 14, 14, C),
+                       mean.float().cuda(), inv.float().cuda(), ga.cuda(), dg, db, False, True, act=2)
+    assert rel(dx.view(M, C), x64.grad) < 1e-5 and rel(dg, g64.grad) < 1e-4 and rel(db, b64.grad) < 1e-5
+
+
+def _model():
+    from imagecaptioner_amd.student_model_compact import CompactCaptioningStudent
+    from imagecaptioner_amd.utils.seeded_init import apply_seeded_init
+    m = apply_seeded_init(CompactCaptioningStudent(5000, 256, 256, 1), 7).cuda()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m
+
+
+def test_compact_student_eval_and_greedy_vs_reference_golden():
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    g = load_golden("compact_student.npz")
+    m = _model().eval()
+    images, caps = synthetic_batch(2, 5000, 16, seed=4321)
+    with torch.no_grad():
+        logits, enc, hids, attw = m(images.cuda(), caps[:-1].cuda())
+    assert rel(enc, g["eval_enc"]) < 2e-4 and rel(logits[:, :, ::10], g["eval_logits"]) < 2e-4
+    assert (logits[:, :, ::10].cpu() - t(g["eval_logits"])).abs().max().item() < 1e-3
+    assert rel(hids[7], g["eval_hid7"]) < 2e-4 and rel(attw[0], g["eval_attw0"]) < 2e-4
+    assert torch.equal(logits.argmax(-1).cpu(), t(g["eval_argmax"]))               # margins > 1e-4 in the golden
+    ids, _ = m.generate(images.cuda(), max_length=12)
+    want = g["greedy_ids"]                                                         # (2, 12), -1 after <END>
+    for b in range(2):
+        n = int((want[b] >= 0).sum())
+        assert ids[:n, b].cpu().tolist() == want[b][:n].tolist()
+        if n < 12:
+            assert int(ids[n, b]) == 2                                            # the reference stopped at <END>
+
+
+def test_compact_student_train_mode_forward_backward_vs_reference_golden():
+    """train mode (batch-statistics BatchNorm in all 52 BatchNorms, dropout 0), B = 2: forward at 1e-3, gradients in relative L2
+    (2 % above the trunk, 6 % through it: the same B = 2 conditioning as the ResNet trunk, see test_kd_step_b16_gpu.py)."""
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    g = load_golden("compact_student.npz")
+    m = _model().train()
+    images, caps = synthetic_batch(2, 5000, 16, seed=4321)
+    logits, enc, hids, attw = m(images.cuda(), caps[:-1].cuda())
+    assert rel(enc, g["train_enc"]) < 1e-3 and rel(logits[:, :, ::10], g["train_logits"]) < 1e-3
+    gen = torch.Generator().manual_seed(77)
+    dl = torch.randn(logits.shape, generator=gen) * 1e-2
+    de = torch.randn(enc.shape, generator=gen) * 1e-2
+    (logits * dl.cuda()).sum().add((enc * de.cuda()).sum()).backward()
+    sd = dict(m.named_parameters())
+    assert all(sd[k].grad is None for k in sd if any(k.startswith(f"encoder.backbone.{i}.") for i in range(10)))
+    assert rel(m.encoder.backbone[0][1].running_mean, g["bn0_running_mean"]) < 1e-4
+    assert rel(m.encoder.backbone[17].conv[3].running_var, g["bn17_running_var"]) < 1e-3
+    errs = {}
+    for k, sl in (("encoder.backbone.18.0.weight", np.s_[::8, ::4, 0, 0]), ("encoder.backbone.17.conv.1.0.weight", np.s_[::4, 0]),
+                  ("encoder.backbone.14.conv.0.0.weight", np.s_[::8, ::4, 0, 0]), ("encoder.backbone.10.conv.2.weight", np.s_[::2, ::8, 0, 0]),
+                  ("encoder.backbone.10.conv.1.1.weight", np.s_[:]), ("encoder.backbone.12.conv.3.bias", np.s_[:]),
+                  ("encoder.projection.0.weight", np.s_[::4, ::16]), ("decoder.attention.weight", np.s_[::4, ::4]),
+                  ("decoder.lstm.weight_hh_l0", np.s_[::16, ::4]), ("decoder.embedding.weight", np.s_[::40, ::4]),
+                  ("decoder.output_projection.weight", np.s_[::40, ::4])):
+        errs[k] = l2(sd[k].grad.detach().cpu()[sl], g["g:" + k])
+    print(errs)
+    for k, e in errs.items():
+        assert e < (6e-2 if k.startswith("encoder.backbone.") else 2e-2), (k, e, errs)

@@ -230,6 +230,44 @@ def test_kd_step_b16_fp32_and_fp64_yardstick():
     assert 1e-3 < worst < 5e-2      # the yardstick itself: reference fp32 vs fp64 through the train-mode trunk
 
 
+def _compact_run(train):
+    trainable = lambda k: not any(k.startswith(f"encoder.backbone.{i}.") for i in range(10)) and "running_" not in k
+    sd = leafs(seeded_state_dict(R.compact_state_shapes(5000, 256, 256), seed=7), trainable)
+    images, caps = synthetic_batch(2, 5000, 16, seed=4321)
+    return sd, images, caps, R.compact_student_forward(sd, images, caps[:-1], hidden=256, train=train)
+
+
+def test_compact_student_restatement_vs_reference_golden():
+    """N4: CompactCaptioningStudent (reference src/student_model_compact.py: MobileNetV2 features, dot-product attention, additive
+    fusion, 1-layer LSTM, Linear(H,V)) — the restatement against outputs and gradients captured from the reference class."""
+    g = load_golden("compact_student.npz")
+    assert sorted(R.compact_state_shapes(5000, 256, 256)) == sorted(k for k in g["keys"].tolist() if "num_batches" not in k)
+    sd, images, caps, (logits, enc, hids, attw) = _compact_run(False)
+    close(logits[:, :, ::10], g["eval_logits"], 1e-4, "eval logits")
+    close(enc, g["eval_enc"], 1e-4, "eval enc")
+    close(hids[7], g["eval_hid7"], 1e-4, "hid7")
+    close(attw[0], g["eval_attw0"], 1e-4, "attw0")
+    assert float(g["eval_margin"].min()) > 1e-4
+    assert torch.equal(logits.argmax(-1), t(g["eval_argmax"]))
+    sd, images, caps, (logits, enc, hids, attw) = _compact_run(True)
+    close(logits[:, :, ::10], g["train_logits"], 1e-4, "train logits")
+    close(enc, g["train_enc"], 1e-4, "train enc")
+    gen = torch.Generator().manual_seed(77)
+    dl = torch.randn(logits.shape, generator=gen) * 1e-2
+    de = torch.randn(enc.shape, generator=gen) * 1e-2
+    (logits * dl).sum().add((enc * de).sum()).backward()
+    assert bool(g["frozen_none"]) and sd["encoder.backbone.3.conv.0.0.weight"].grad is None
+    close(sd["encoder.backbone.0.1.running_mean"], g["bn0_running_mean"], 1e-4, "bn0 running mean (frozen modules still update)")
+    close(sd["encoder.backbone.17.conv.3.running_var"], g["bn17_running_var"], 1e-4, "bn17 running var")
+    import numpy as _np
+    for k, sl in (("encoder.backbone.18.0.weight", _np.s_[::8, ::4, 0, 0]), ("encoder.backbone.17.conv.1.0.weight", _np.s_[::4, 0]),
+                  ("encoder.backbone.10.conv.2.weight", _np.s_[::2, ::8, 0, 0]), ("encoder.projection.0.weight", _np.s_[::4, ::16]),
+                  ("decoder.attention.weight", _np.s_[::4, ::4]), ("decoder.lstm.weight_hh_l0", _np.s_[::16, ::4]),
+                  ("decoder.output_projection.weight", _np.s_[::40, ::4])):
+        close(sd[k].grad[sl], g["g:" + k], 2e-3, k)
+    assert int(g["total_params"]) == sum(int(_np.prod(v)) for k, v in R.compact_state_shapes(5000, 256, 256).items() if "running" not in k)
+
+
 @pytest.mark.parametrize("epoch", [0, 1, 3, 7])
 def test_optimized_distillation_loss(golden, epoch):
     """N4: oracle restatement of the reference's OptimizedDistillationLoss vs goldens captured from the reference class."""

@@ -43,11 +43,11 @@ for (nb, h, c, bwd) in ((64, 56, 64, False), (64, 56, 256, False), (64, 28, 128,
         L = ops._lib.lib()
         st = ops._st
         t_red = timeit(lambda: L.ick_bn_bwd_reduce(raw.data_ptr(), res.data_ptr(), raw.data_ptr(), mean.data_ptr(), inv.data_ptr(),
-                                                   sums[0].data_ptr(), sums[1].data_ptr(), ops.BN_BWD_COPIES, c, M, c, st()))
+                                                   sums[0].data_ptr(), sums[1].data_ptr(), ops.BN_BWD_COPIES, c, M, c, 1, st()))
         dx = torch.empty_like(raw)
         coef = torch.empty(2, c, device="cuda")
         t_ba = timeit(lambda: L.ick_bn_bwd_apply(raw.data_ptr(), res.data_ptr(), raw.data_ptr(), mean.data_ptr(), inv.data_ptr(),
                                                  g.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), ops.BN_BWD_COPIES, c,
-                                                 coef.data_ptr(), dx.data_ptr(), None, M, c, 1, dg.data_ptr(), db.data_ptr(), st()))
+                                                 coef.data_ptr(), dx.data_ptr(), None, M, c, 1, dg.data_ptr(), db.data_ptr(), 1, st()))
         line += f" {t_red:9.1f} {M * c * 12 / t_red / 1e3:6.0f} | {t_ba:12.1f} {M * c * 16 / t_ba / 1e3:6.0f}"
     print(line)
