@@ -116,7 +116,7 @@ def test_compact_student_train_mode_forward_backward_vs_reference_golden():
     errs = {}
     for k, sl in (("encoder.backbone.18.0.weight", np.s_[::8, ::4, 0, 0]), ("encoder.backbone.17.conv.1.0.weight", np.s_[::4, 0]),
                   ("encoder.backbone.14.conv.0.0.weight", np.s_[::8, ::4, 0, 0]), ("encoder.backbone.10.conv.2.weight", np.s_[::2, ::8, 0, 0]),
-                  ("encoder.backbone.10.conv.1.1.weight", np.s_[:]), ("encoder.backbone.12.conv.3.bias", np.s_[:]),
+                  ("encoder.backbone.10.conv.1.1.weight", np.s_[:]), ("encoder.backbone.12.conv.3.weight", np.s_[:]),
                   ("encoder.projection.0.weight", np.s_[::4, ::16]), ("decoder.attention.weight", np.s_[::4, ::4]),
                   ("decoder.lstm.weight_hh_l0", np.s_[::16, ::4]), ("decoder.embedding.weight", np.s_[::40, ::4]),
                   ("decoder.output_projection.weight", np.s_[::40, ::4])):
