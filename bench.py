@@ -105,25 +105,26 @@ def cpu_baseline(batch: int = BATCH, budget_s: float = 20.0):
     leaves = [v for v in list(ssd.values()) + list(psd.values()) if v.requires_grad]
 
     def timed(fn, min_steps, budget):
-        steps, t0 = 0, time.perf_counter()
-        while steps < min_steps or (time.perf_counter() - t0 < budget and steps < 40):
+        """per-call seconds of `fn`, at least min_steps calls, stopping after ~budget seconds"""
+        ts, t_start = [], time.perf_counter()
+        while len(ts) < min_steps or (time.perf_counter() - t_start < budget and len(ts) < 40):
+            t0 = time.perf_counter()
             fn()
-            steps += 1
-        return steps, time.perf_counter() - t0
+            ts.append(time.perf_counter() - t0)
+        return ts
 
     def step():
         for v in leaves:
             v.grad = None
         run()
 
-    def step_dup():                         # + the reference's redundant second ViT pass (no grad)
-        step()
+    def vit_again():                        # the reference's redundant second ViT pass (no grad), distillation_utils.py:278-282
         with torch.no_grad():
             R.vit_small_features(tsd, "encoder", images)
 
     step()                                  # warm-up (thread pools, allocator)
-    n1, t1 = timed(step, 2, budget_s * 0.55)
-    n2, t2 = timed(step_dup, 1, budget_s * 0.3)
+    t_step = timed(step, 2, budget_s * 0.7)
+    t_vit = timed(vit_again, 1, budget_s * 0.15)
     opt = torch.optim.AdamW([{"params": [v for k, v in ssd.items() if v.requires_grad and k.startswith("encoder.")], "lr": 2e-5},
                              {"params": [v for k, v in ssd.items() if v.requires_grad and not k.startswith("encoder.")] +
                                         [v for v in psd.values() if v.requires_grad], "lr": 2e-4}], weight_decay=0.01)
@@ -134,12 +135,15 @@ def cpu_baseline(batch: int = BATCH, budget_s: float = 20.0):
         opt.step()
 
     opt_step()
-    n3, t3 = timed(opt_step, 3, 1.0)
-    return {"value": round(batch * n1 / t1, 3), "unit": "images/s", "cores": cores, "cpu_model": model, "kind": "port",
-            "value_as_reference_executes": round(batch * n2 / t2, 3), "optimizer_ms_per_step": round(t3 / n3 * 1e3, 2),
-            "sample": f"{n1} steps of batch {batch} (teacher fwd + student fwd + KD loss + bwd, fp32, single ViT pass, no "
-                      f"optimizer) on {cores} threads; value_as_reference_executes: {n2} steps with the reference's duplicate "
-                      f"ViT pass; optimizer (2x clip_grad_norm_ + AdamW) timed separately over {n3} steps; torch {torch.__version__} CPU eager"}
+    t_opt = timed(opt_step, 3, 1.0)
+    mean = lambda xs: sum(xs) / len(xs)
+    ts, tv = mean(t_step), mean(t_vit)
+    return {"value": round(batch / ts, 3), "unit": "images/s", "cores": cores, "cpu_model": model, "kind": "port",
+            "value_as_reference_executes": round(batch / (ts + tv), 3), "optimizer_ms_per_step": round(mean(t_opt) * 1e3, 2),
+            "sample": f"{len(t_step)} steps of batch {batch} (teacher fwd + student fwd + KD loss + bwd, fp32, single ViT pass, no "
+                      f"optimizer) on {cores} threads, mean {ts:.2f} s/step; value_as_reference_executes adds the reference's "
+                      f"duplicate ViT pass ({tv:.2f} s, {len(t_vit)} timed) to the same step time; optimizer (2x clip_grad_norm_ + "
+                      f"AdamW) timed separately over {len(t_opt)} steps; torch {torch.__version__} CPU eager"}
 
 
 def run_kd(args, precision, dev, rank, world, log):
