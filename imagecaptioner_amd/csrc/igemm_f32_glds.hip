@@ -1,565 +1,10 @@
-// igemm_f32_glds.hip — the exact-fp32 MFMA implicit-GEMM family with DIRECT global->LDS staging (LDS-DMA,
-// global_load_lds_dwordx4) instead of register staging.
-//
-// Why: an ablation of the register-staged kernel (igemm_f32.hip; tools/ablate, profiles/r01g_ablation_f32.log) on MI355X
-// shows the MFMA loop alone runs at 142 TF (90 % of the fp32 MFMA peak) but the full kernel at 102 TF: issuing the
-// global loads + exposed load latency cost 18-25 % and the register->LDS write pass (ds_write, zero-masking VALU)
-// another 10-15 %.  LDS-DMA removes both: no staging VGPRs, no ds_write instructions, and a k-tile twice as deep (32)
-// so that one tile of prefetch covers the load latency.
-//
-//   C[z][m][n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) + residual[m][n]        (same contract as igemm_f32.hip)
-//
-// LDS images (one LDS-DMA wave-instruction writes 64 lanes x 16 B = 1 KiB, lane-linear):
-//   * k-contiguous source: image [x][32 k] (128-B rows, 8 sixteen-byte chunks), chunk position XOR-swizzled by
-//     (row>>1)&7 THROUGH THE SOURCE ADDRESS (lane l of the DMA fetches the chunk that belongs at its linear slot).
-//     Fragment = one ds_read_b128 per 32x32 tile per 8 k: lane l reads A[row l&31][8j + 4(l>>5) + 0..3]; MFMA e of the
-//     group multiplies k-slots {8j+e, 8j+4+e} — the SAME k pairing on the A and the B side, so the sum is unchanged.
-//     With the swizzle the four 16-lane groups of ds_read_b128 each touch 16 distinct 16-B slots: conflict-free.
-//   * x-contiguous source: image [32 k][x] (lane-linear as is), fragment = ds_read_b32 per k (32 consecutive floats).
-// Out-of-range elements (conv padding, M/N/K tails) are fetched from a 16-byte zero page instead of being masked
-// afterwards.  Two LDS buffers, one barrier per k-tile:  wait own DMA -> barrier -> issue DMA of tile t+1 -> MFMAs of t.
-#include "igemm_params.h"
-#include <cstdlib>
-#include <type_traits>
-#ifndef ICK_ABL
-#define ICK_ABL 0   // tools/ablate builds set 1..3 to price the epilogue and the DMA stream (never in libick.so)
-#endif
-
-namespace {
-
-using namespace ickg;
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;
-constexpr int NT = 256;
-
-__device__ __attribute__((aligned(16))) float g_zero16[4];   // the zero page
-const bool g_no_vec_epilogue = [] { const char* e = getenv("ICK_NO_VEC_EPILOGUE"); return e && e[0] == '1'; }();   // A/B runs
-
-// One LDS-DMA wave-instruction: lane l's 16 bytes at `src` land at LDS byte address lds_wave_base + 16*l.
-// Issued through inline asm on purpose: hipcc tracks the builtin form as an LDS write on the VM counter and then
-// waits vmcnt(0) in front of EVERY later ds_read (it cannot prove the other LDS buffer does not alias), which
-// serialises "load tile t+1" against "compute tile t".  The k-loop has no other vector-memory loads, so the only
-// vmcnt wait that matters is the explicit one at the top of each iteration.
-__device__ __forceinline__ void glds16(const float* src, unsigned lds_wave_base) {
-  const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);
-#if ICK_ABL == 5   // timing experiment: every DMA is issued but fetches the zero page (issue cost without operand traffic)
-  src = g_zero16;
-#endif
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory");
-}
-
-template <int OP, int BM, int BN, int NBUF>
-__global__ __launch_bounds__(NT, 2) void igemm_f32_glds_kernel(const P p) {
-  constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int PA = BM / 32, PB = BN / 32;            // LDS-DMA instructions per thread per k-tile
-  constexpr int A_SZ = BM * BK, B_SZ = BN * BK, BUF = A_SZ + B_SZ;
-  constexpr int A_TPK = BM / 4, B_TPK = BN / 4;        // lanes per k-row of an x-contiguous image
-  constexpr int A_RPI = 64 / A_TPK, B_RPI = 64 / B_TPK;  // k-rows per DMA instruction (x-contiguous)
-
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;   // XCD-aware tile order (igemm_f32.hip)
-  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
-  const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
-  const int m0 = p.m_base + tile_m * BM, n0 = tile_n * BN;   // m_base: first row of this launch (M-split dispatch)
-
-  int z = blockIdx.z, split = 0;
-  if (p.splitk > 1) { split = z; z = 0; }
-  int py = 0, px = 0, r0 = 0, s0 = 0, ns = 1, kcls = 0;
-  if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
-    py = z >> 1; px = z & 1; z = 0;
-    r0 = (py + p.pad) & 1; s0 = (px + p.pad) & 1;
-    const int nr = p.R > r0 ? (p.R - r0 + 1) / 2 : 0;
-    ns = p.S > s0 ? (p.S - s0 + 1) / 2 : 0;
-    kcls = nr * ns * p.Cout;
-  }
-  const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
-  const float* __restrict__ Ag = p.A + zo * p.sAo + zi * p.sAi;
-  const float* __restrict__ Bg = p.B + zo * p.sBo + zi * p.sBi;
-  const long coff = zo * p.sCo + zi * p.sCi;
-  const int kbeg = split * p.kps;
-  const int kend = OP == ICK_OP_CONV_DGRAD_S2 ? kcls : min(p.K, kbeg + p.kps);
-  const int nkt = (kend - kbeg + BK - 1) / BK;
-
-  // ---------------------------------------------------------------- per-thread DMA state
-  // k-contiguous: DMA instruction q = wave*P + i covers rows 8q..8q+7; lane l -> row 8q + (l>>3), linear chunk slot l&7,
-  // which holds logical chunk (l&7) ^ ((row>>1)&7).
-  const float* a_ptr[PA]; bool a_ok[PA]; int a_y[PA], a_x[PA], a_kq[PA];
-#pragma unroll
-  for (int i = 0; i < PA; ++i) {
-    const int q = wave * PA + i;
-    if constexpr (AK) {
-      const int row = q * 8 + (lane >> 3);
-      a_kq[i] = (((lane & 7) ^ ((row >> 1) & 7)) << 2);
-      const int m = m0 + row;
-      a_ok[i] = m < p.M;
-      if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
-        a_ptr[i] = Ag + (long)m * p.lda + a_kq[i]; a_y[i] = a_x[i] = 0;
-      } else if constexpr (OP == ICK_OP_CONV_FWD || OP == ICK_OP_CONV_FWD_C4) {
-        const int hw = p.Ho * p.Wo; const int b = m / hw; const int r = m - b * hw;
-        const int oy = r / p.Wo, ox = r - oy * p.Wo;
-        a_y[i] = oy * p.stride - p.pad; a_x[i] = ox * p.stride - p.pad;
-        a_ptr[i] = Ag + (long)b * p.H * p.W * p.Cin;
-      } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
-        const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int r = m - b * hw;
-        const int iy = 2 * (r / w2) + py, ix = 2 * (r % w2) + px;
-        a_y[i] = iy + p.pad; a_x[i] = ix + p.pad;
-        a_ptr[i] = Ag + (long)b * p.Ho * p.Wo * p.Cout;
-      } else {  // CONV_DGRAD
-        const int hw = p.H * p.W; const int b = m / hw; const int r = m - b * hw;
-        const int iy = r / p.W, ix = r - iy * p.W;
-        a_y[i] = iy + p.pad; a_x[i] = ix + p.pad;
-        a_ptr[i] = Ag + (long)b * p.Ho * p.Wo * p.Cout;
-      }
-    } else {  // A stored [K][M]: instruction q covers k-rows q*A_RPI .. ; lane -> (k-row, 4 m)
-      const int m = m0 + (lane % A_TPK) * 4;
-      a_ok[i] = m < p.M;
-      a_ptr[i] = Ag + m; a_y[i] = q * A_RPI + lane / A_TPK; a_x[i] = 0; a_kq[i] = 0;
-    }
-  }
-  const float* b_ptr[PB]; bool b_ok[PB]; int b_y[PB], b_kq[PB];
-  int b_r = 0, b_s = 0;
-#pragma unroll
-  for (int i = 0; i < PB; ++i) {
-    const int q = wave * PB + i;
-    if constexpr (BKc) {
-      const int row = q * 8 + (lane >> 3);
-      b_kq[i] = (((lane & 7) ^ ((row >> 1) & 7)) << 2);
-      const int n = n0 + row;
-      b_ok[i] = n < p.N;
-      b_ptr[i] = Bg + (long)n * p.ldb + b_kq[i]; b_y[i] = 0;
-    } else {
-      const int n = n0 + (lane % B_TPK) * 4;
-      b_ok[i] = n < p.N;
-      b_y[i] = q * B_RPI + lane / B_TPK; b_kq[i] = 0;
-      if constexpr (OP == ICK_OP_CONV_WGRAD) {
-        const int tap = n / p.Cin; const int ci = n - tap * p.Cin;
-        b_r = tap / p.S; b_s = tap - b_r * p.S;
-        b_ptr[i] = Bg + ci;
-      } else {
-        b_ptr[i] = Bg + n;
-      }
-    }
-  }
-
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
-  // issue the LDS-DMA of k-tile kt into buffer buf
-  auto issue = [&](int kt, int buf) {
-    const int k0 = kbeg + kt * BK;
-    const unsigned Ab = lds_base + 4u * (buf * BUF + wave * (PA * 256));       // LDS byte addresses (wave-uniform)
-    const unsigned Bb = lds_base + 4u * (buf * BUF + A_SZ + wave * (PB * 256));
-    if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const bool ok = a_ok[i] && (k0 + a_kq[i] < kend);
-        glds16(ok ? a_ptr[i] + k0 : g_zero16, Ab + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_FWD) {
-      const int tap = k0 / p.Cin; const int ci0 = k0 - tap * p.Cin;
-      const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int iy = a_y[i] + r, ix = a_x[i] + s;
-        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (k0 + a_kq[i] < kend);
-        glds16(ok ? a_ptr[i] + ((long)iy * p.W + ix) * p.Cin + ci0 + a_kq[i] : g_zero16, Ab + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_FWD_C4) {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int tap = (k0 + a_kq[i]) >> 2; const int r = tap / p.S, s = tap - r * p.S;
-        const int iy = a_y[i] + r, ix = a_x[i] + s;
-        const bool ok = a_ok[i] && r < p.R && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        glds16(ok ? a_ptr[i] + ((long)iy * p.W + ix) * 4 : g_zero16, Ab + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
-      const int tap = k0 / p.Cout; const int co0 = k0 - tap * p.Cout;
-      const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int ty = a_y[i] - r, tx = a_x[i] - s;
-        const int oy = ty / p.stride, ox = tx / p.stride;
-        const bool ok = a_ok[i] && ty >= 0 && tx >= 0 && oy * p.stride == ty && ox * p.stride == tx &&
-                        oy < p.Ho && ox < p.Wo && (k0 + a_kq[i] < kend);
-        glds16(ok ? a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co0 + a_kq[i] : g_zero16, Ab + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
-      const int q = k0 / p.Cout; const int co0 = k0 - q * p.Cout;
-      const int r = r0 + 2 * (q / ns), s = s0 + 2 * (q % ns);
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int ty = a_y[i] - r, tx = a_x[i] - s;
-        const int oy = ty >> 1, ox = tx >> 1;
-        const bool ok = a_ok[i] && ty >= 0 && tx >= 0 && oy < p.Ho && ox < p.Wo && (k0 + a_kq[i] < kend);
-        glds16(ok ? a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co0 + a_kq[i] : g_zero16, Ab + i * 1024);
-      }
-    } else {  // A [K][M]
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int k = k0 + a_y[i];
-        const bool ok = a_ok[i] && k < kend;
-        glds16(ok ? a_ptr[i] + (long)k * p.lda : g_zero16, Ab + i * 1024);
-      }
-    }
-    if constexpr (BKc) {
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const bool ok = b_ok[i] && (k0 + b_kq[i] < kend);
-        glds16(ok ? b_ptr[i] + k0 : g_zero16, Bb + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
-      const int tap = k0 / p.Cout; const int co0 = k0 - tap * p.Cout;
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int co = co0 + b_y[i];
-        const bool ok = b_ok[i] && (k0 + b_y[i] < kend);
-        glds16(ok ? b_ptr[i] + ((long)co * p.R * p.S + tap) * p.Cin : g_zero16, Bb + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
-      const int q = k0 / p.Cout; const int co0 = k0 - q * p.Cout;
-      const int tap = (r0 + 2 * (q / ns)) * p.S + s0 + 2 * (q % ns);
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int co = co0 + b_y[i];
-        const bool ok = b_ok[i] && (k0 + b_y[i] < kend);
-        glds16(ok ? b_ptr[i] + ((long)co * p.R * p.S + tap) * p.Cin : g_zero16, Bb + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_WGRAD) {
-      const int hw = p.Ho * p.Wo;
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int k = k0 + b_y[i];
-        const int b = k / hw; const int rem = k - b * hw; const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        const int iy = oy * p.stride - p.pad + b_r, ix = ox * p.stride - p.pad + b_s;
-        const bool ok = b_ok[i] && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        glds16(ok ? b_ptr[i] + (((long)b * p.H + iy) * p.W + ix) * p.Cin : g_zero16, Bb + i * 1024);
-      }
-    } else {  // B [K][N]
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int k = k0 + b_y[i];
-        const bool ok = b_ok[i] && k < kend;
-        glds16(ok ? b_ptr[i] + (long)k * p.ldb : g_zero16, Bb + i * 1024);
-      }
-    }
-  };
-
-  // fragments of k-group j (8 k) of tile-row/column t: element e feeds MFMA e (k-slots {8j+e, 8j+4+e})
-  const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
-  auto frag_a = [&](const float* Ab, int j, int i) -> float4 {
-    if constexpr (AK) {
-      return *reinterpret_cast<const float4*>(Ab + (wm * WM + i * 32 + frow) * BK + (((2 * j + fh) ^ fsw) << 2));
-    } else {
-      const float* q = Ab + (8 * j + 4 * fh) * BM + wm * WM + i * 32 + frow;
-      return make_float4(q[0], q[BM], q[2 * BM], q[3 * BM]);
-    }
-  };
-  auto frag_b = [&](const float* Bb, int j, int t) -> float4 {
-    if constexpr (BKc) {
-      return *reinterpret_cast<const float4*>(Bb + (wn * WN + t * 32 + frow) * BK + (((2 * j + fh) ^ fsw) << 2));
-    } else {
-      const float* q = Bb + (8 * j + 4 * fh) * BN + wn * WN + t * 32 + frow;
-      return make_float4(q[0], q[BN], q[2 * BN], q[3 * BN]);
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // Chunked accumulation: one MFMA accumulator is a strictly sequential fp32 chain over k, whose rounding error grows
-  // with the chain length (measured: a K = 4608 chain is 4x further from fp64 than a K-blocked CPU GEMM, and that excess
-  // shows up 1.5-3x in every gradient behind the ResNet trunk).  Every p.chunk_tiles k-tiles (64 k by default; CPU
-  // GEMMs block K at ~256) the chain is folded into a master sum and restarted from zero.  Measured on the KD step
-  // (tools/diag_grads.py, profiles/r02_diag_grads_B{2,8}.log, chunk 128): gradient error vs fp64 relative to torch's
-  // CPU fp32 falls from 4.3-4.5x (refinement / decoder, B = 8) to 0.98x, trunk 1.10x -> 0.92x; an isolated K = 2304
-  // data gradient goes from 1.8e-6 to 2.6e-7 of scale.  Cost: none measurable (29.83 vs 29.81 ms/step at chunk 64 / 128,
-  // 194.3 vs 195.1 us for the ViT fc1 GEMM with / without folding): the fold's VALU adds hide under other waves' MFMAs.
-  f32x16 tot[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
-  int chain = 0;
-
-  // NBUF = 2: DMA of tile t+1 is issued at the top of iteration t (one compute phase to land).
-  // NBUF = 3: DMA of tile t+2 is issued at the top of iteration t (two compute phases to land); the wait at the top of
-  //           iteration t leaves the PA+PB most recent DMAs (tile t+1) in flight.
-  if (nkt > 0) issue(0, 0);
-  if (NBUF == 3 && nkt > 1) issue(1, 1);
-  int cb = 0;                                     // buffer of tile kt
-  for (int kt = 0; kt < nkt; ++kt) {
-    // my DMA of tile kt has landed; after the barrier so has everybody's, and everybody is done reading the buffer
-    // that the next DMA overwrites
-    if (NBUF == 3 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-#if ICK_ABL == 3
-    if (kt + NBUF - 1 < nkt && p.alpha == 12345.f) issue(kt + NBUF - 1, cb == 0 ? NBUF - 1 : cb - 1);
-#else
-    if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1, cb == 0 ? NBUF - 1 : cb - 1);
-#endif
-    const float* Ab = lds + cb * BUF;
-    cb = cb + 1 == NBUF ? 0 : cb + 1;
-    const float* Bb = Ab + A_SZ;
-    float4 av[2][TM], bv[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) av[0][i] = frag_a(Ab, 0, i);
-#pragma unroll
-    for (int t = 0; t < TN; ++t) bv[0][t] = frag_b(Bb, 0, t);
-#pragma unroll
-    for (int j = 0; j < BK / 8; ++j) {
-      const int cur = j & 1, nxt = cur ^ 1;
-      if (j + 1 < BK / 8) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) av[nxt][i] = frag_a(Ab, j + 1, i);
-#pragma unroll
-        for (int t = 0; t < TN; ++t) bv[nxt][t] = frag_b(Bb, j + 1, t);
-      }
-      // keep the next group's LDS reads AHEAD of this group's MFMAs (hipcc otherwise sinks them behind the MFMAs and
-      // exposes the LDS latency at the head of every group)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].x, bv[cur][t].x, acc[i][t], 0, 0, 0);
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].y, bv[cur][t].y, acc[i][t], 0, 0, 0);
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].z, bv[cur][t].z, acc[i][t], 0, 0, 0);
-          acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].w, bv[cur][t].w, acc[i][t], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (++chain == p.chunk_tiles && kt + 1 < nkt) {
-      chain = 0;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-          tot[i][t] += acc[i][t];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
-        }
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t];
-
-  // ---------------------------------------------------------------- epilogue
-  // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-  // Interior tiles (the vast majority) take a check-free path; flags are wave-uniform scalars.
-  float* __restrict__ Cg = p.C + coff;
-  const float* __restrict__ Rg = (p.residual && split == 0) ? p.residual + coff : nullptr;
-  const float* __restrict__ biasp = (p.bias && split == 0) ? p.bias : nullptr;
-  const int mode = p.splitk > 1 ? 2 : (p.accumulate ? 1 : 0);
-  const int act = p.act & 15;
-  const bool post = (p.act & ICK_ACT_POST_RESIDUAL) != 0;   // activation after the residual (staged epilogue only)
-  const float alpha = p.alpha;
-  if (p.ep_vec && mode != 2) {
-    // LDS-staged epilogue: the block tile goes registers -> LDS (bias / activation applied, statistics taken on the
-    // way) and leaves as 16-byte stores along n, 2 x 512-byte rows (128-wide tiles) per wave-instruction instead of
-    // 2 x 128 bytes: the direct path below issues 4x the store instructions and prices 5-30 % of a short-K GEMM
-    // (profiles/r01g_ablation_glds.log, V1 -> V2).  The residual is read in the same coalesced pattern.
-    __syncthreads();                       // every wave is out of the k-loop: the LDS buffers become the C tile [BM][BN]
-    float* ct = lds;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int nl = wn * WN + j * 32 + (lane & 31);
-      const int n = n0 + nl;
-      const bool nok = n < p.N;
-      const float bias = (biasp && nok) ? biasp[n] : 0.f;
-      const float csc = (p.col_scale && nok) ? p.col_scale[n] : 1.f;   // eval-mode BatchNorm scale (else exactly v + bias)
-      float ssum = 0.f, ssq = 0.f;   // ssq by explicit fmaf: the epilogue variants must agree bit for bit
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int ml = wm * WM + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = ml + (r & 3) + 8 * (r >> 2);
-          const float v = acc[i][j][r] * alpha;
-          if (nok && m0 + row < p.M) { ssum += v; ssq = fmaf(v, v, ssq); }
-          const float u = fmaf(v, csc, bias);
-          ct[row * BN + nl] = post ? u : act_fn(u, act);
-        }
-      }
-      if (p.stat_sum) {
-        ssum += __shfl_xor(ssum, 32);
-        ssq += __shfl_xor(ssq, 32);
-        if (lane < 32 && nok) {
-          const long so = (long)(tile_m % p.stat_copies) * p.stat_stride + n;
-          atomicAdd(p.stat_sum + so, (double)ssum); atomicAdd(p.stat_sq + so, (double)ssq);
-        }
-      }
-    }
-    __syncthreads();
-    constexpr int C4 = BN / 4;
-    for (int c = tid; c < BM * C4; c += NT) {
-      const int row = c / C4, col = (c - row * C4) * 4;
-      const int m = m0 + row, n = n0 + col;
-      if (m < p.M && n < p.N) {            // N % 4 == 0 on this path: the whole chunk is in range
-        long mr = m;
-        if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
-          const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
-          mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
-        }
-        float4 v = *reinterpret_cast<const float4*>(ct + row * BN + col);
-        if (Rg) {
-          const float4 q = *reinterpret_cast<const float4*>(Rg + mr * p.ldr + n);
-          v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-        }
-        if (post) { v.x = act_fn(v.x, act); v.y = act_fn(v.y, act); v.z = act_fn(v.z, act); v.w = act_fn(v.w, act); }
-        float4* dst = reinterpret_cast<float4*>(Cg + mr * p.ldc + n);
-        if (mode == 1) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *dst = v;
-      }
-    }
-    return;
-  }
-  auto epilogue = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WN + j * 32 + (lane & 31);
-      const bool nok = FULL || n < p.N;
-      const float bias = (biasp && nok) ? biasp[n] : 0.f;
-      float ssum = 0.f, ssq = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int mb = m0 + wm * WM + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mb + (r & 3) + 8 * (r >> 2);
-          if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL >= 4 || alpha == 12345.f)) {
-            float v = acc[i][j][r] * alpha;
-            ssum += v; ssq = fmaf(v, v, ssq);
-            v = act_fn(v + bias, act);
-            long mr = m;
-            if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // class row -> pixel row of the full-resolution dX
-              const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
-              mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
-            }
-            const long o = mr * p.ldc + n;
-            if (Rg) v += Rg[mr * p.ldr + n];
-            if (mode == 2) atomicAdd(Cg + o, v);
-            else if (mode == 1) Cg[o] += v;
-            else Cg[o] = v;
-          }
-        }
-      }
-      if (p.stat_sum && (ICK_ABL < 1 || ICK_ABL >= 4 || alpha == 12345.f)) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
-        ssum += __shfl_xor(ssum, 32);
-        ssq += __shfl_xor(ssq, 32);
-        if (lane < 32 && nok) {
-          const long so = (long)(tile_m % p.stat_copies) * p.stat_stride + n;   // copy of this row tile
-#if ICK_ABL == 4   // timing experiment only: fp32 atomics instead of fp64
-          atomicAdd(reinterpret_cast<float*>(p.stat_sum) + so, ssum); atomicAdd(reinterpret_cast<float*>(p.stat_sq) + so, ssq);
-#else
-          atomicAdd(p.stat_sum + so, (double)ssum); atomicAdd(p.stat_sq + so, (double)ssq);
-#endif
-        }
-      }
-    }
-  };
-  if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{});
-  else epilogue(std::false_type{});
-}
-
-// rows [m_begin, m_end) of the problem (m_end <= 0: all of M).  A launch over a row range is what the M-split dispatch
-// uses: bounds are checked against p.M = m_end, addresses are formed from the global row index.
-template <int OP, int BM, int BN, int NBUF>
-int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) {
-  P p = p0;
-  if (m_end <= 0 || m_end > p.M) m_end = p.M;
-  p.m_base = m_begin;
-  p.M = m_end;
-  p.tiles_n = (p.N + BN - 1) / BN;
-  // 16-byte stores need every row start of C (and of the residual) 16-byte aligned
-  p.ep_vec = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.sCo | p.sCi) % 4 == 0 && ick::aligned16(p.C) &&
-             (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual))) && !g_no_vec_epilogue && !p.no_ep_vec;
-  if ((p.col_scale || (p.act & ICK_ACT_POST_RESIDUAL)) && !(p.ep_vec && p.splitk == 1))
-    return ick::fail(-1, "igemm: col_scale / ICK_ACT_POST_RESIDUAL need 16-byte aligned C rows (N %% 4, ldc %% 4) and no split-K");
-  dim3 grid(p.tiles_n * ((p.M - m_begin + BM - 1) / BM), 1, nz);
-  ICK_LAUNCH((igemm_f32_glds_kernel<OP, BM, BN, NBUF>), grid, dim3(NT), 0, st, p);
-  return ick::launch_status("igemm_f32_glds");
-}
-
-constexpr int kCUs = 256;            // MI355X
-constexpr int kBodySlots = 2 * kCUs; // 128x128 workgroups resident at once (64 KiB of LDS each: two per CU)
-
-template <int OP>
-int launch_tile(const P& p, int nz, hipStream_t st, int tile, int m_begin = 0, int m_end = 0) {
-  switch (tile) {           // +16: three LDS buffers (two tiles of prefetch) instead of two
-    case 2: return launch<OP, 64, 64, 2>(p, nz, st, m_begin, m_end);
-    case 3: return launch<OP, 128, 64, 2>(p, nz, st, m_begin, m_end);
-    case 4: return launch<OP, 64, 128, 2>(p, nz, st, m_begin, m_end);
-    case 18: return launch<OP, 64, 64, 3>(p, nz, st, m_begin, m_end);
-    case 19: return launch<OP, 128, 64, 3>(p, nz, st, m_begin, m_end);
-    case 20: return launch<OP, 64, 128, 3>(p, nz, st, m_begin, m_end);
-    default: return launch<OP, 128, 128, 2>(p, nz, st, m_begin, m_end);
-  }
-}
-
-// M-split (IckGemm.tile +32): the 128x128 tile is the family's most efficient at long K (half the operand stream per FLOP
-// of the 64x64 one: 119-127 TF against ~80 at 4096^3) but a grid of T such workgroups runs in ceil(T / 512) rounds, and
-// the step's shapes leave the last round mostly empty (ViT: M = 12608 -> 2.32 rounds).  So: the rows that fill WHOLE
-// rounds go to the 128x128 kernel, the remaining rows to a second launch with a small tile whose own partial round is
-// short.  Measured (profiles/r02b_step_gemm_shapes_tile_sweep.log): a wash on the step's short-K shapes — the ViT fc1
-// GEMM takes 177 us split vs 175 (128x128 alone) vs 166-169 (64-row tiles): with K = 384 a 128x128 workgroup spends as
-// long in its prologue + GELU epilogue as two of its twelve k-tiles, and only two of them share a CU — it wins 2-3 % on
-// the K >= 512 Linear shapes (fc2, teacher decoder).  Kept as a tuned-table option, not chosen by the cost model.
-// Returns the first row of the tail (0: no full round exists -> everything is tail; M: no tail).
-inline int msplit_row(const P& p, int nz) {
-  if (nz != 1) return 0;
-  const long tiles_n = (p.N + 127) / 128, tiles_m = (p.M + 127) / 128;
-  const long rounds = tiles_m * tiles_n / kBodySlots;
-  long rows = rounds * kBodySlots / tiles_n;                 // tile rows of the body
-  if (rows >= tiles_m) return p.M;
-  return (int)(rows * 128);
-}
-
-template <int OP>
-int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
-  static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
-  static const double eff[4] = {1.00, 0.85, 0.93, 0.93};   // relative efficiency of the tile shape
-  bool split = (tile & 32) != 0;
-  tile &= 31;
-  if (tile == 0) {
-    double best = 1e300;
-    auto cost_of = [&](int t, long rows) {                   // busiest CU's share of tile area / efficiency
-      const long blocks = ((rows + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * nz;
-      return (double)((blocks + kCUs - 1) / kCUs) * bm[t] * bn[t] / eff[t];
-    };
-    for (int t = 0; t < 4; ++t) {
-      const double cost = cost_of(t, p.M);
-      if (cost < best * 0.999) { best = cost; tile = t + 1; }
-    }
-  }
-  if (split && OP != ICK_OP_CONV_DGRAD_S2) {
-    const int ms = msplit_row(p, nz);
-    if (ms >= p.M) return launch<OP, 128, 128, 2>(p, nz, st);
-    if (ms > 0) {
-      if (int rc = launch<OP, 128, 128, 2>(p, nz, st, 0, ms)) return rc;
-      return launch_tile<OP>(p, nz, st, tile, ms, p.M);
-    }
-  }
-  return launch_tile<OP>(p, nz, st, tile);
-}
-
-}  // namespace
+// exact-fp32 instantiation (TERMS 0, v_mfma_f32_32x32x2_f32) of the LDS-DMA GEMM family + the eligibility rule shared by all variants.
+// tools/ablate builds this file with -DICK_ABL=n.
+#define ICK_GLDS_TERMS 0
+#define ICK_GLDS_ENTRY run_glds
+#include "igemm_glds_impl.h"
 
 namespace ickg {
-
 // true when the LDS-DMA kernel can run this problem (16-byte chunks must not straddle the K end or a filter tap)
 bool glds_eligible(const IckGemm* d) {
   switch (d->op) {
@@ -571,20 +16,4 @@ bool glds_eligible(const IckGemm* d) {
     default: return false;
   }
 }
-
-// argument checks are done by the caller (ick_gemm_f32); p/nz come from prepare(d, 32, ...)
-int run_glds(const IckGemm* d, const P& p, int nz, hipStream_t st) {
-  switch (d->op) {
-    case ICK_OP_NT: return dispatch_tile<ICK_OP_NT>(p, nz, st, d->tile);
-    case ICK_OP_NN: return dispatch_tile<ICK_OP_NN>(p, nz, st, d->tile);
-    case ICK_OP_TN: return dispatch_tile<ICK_OP_TN>(p, nz, st, d->tile);
-    case ICK_OP_CONV_FWD: return dispatch_tile<ICK_OP_CONV_FWD>(p, nz, st, d->tile);
-    case ICK_OP_CONV_FWD_C4: return dispatch_tile<ICK_OP_CONV_FWD_C4>(p, nz, st, d->tile);
-    case ICK_OP_CONV_DGRAD: return dispatch_tile<ICK_OP_CONV_DGRAD>(p, nz, st, d->tile);
-    case ICK_OP_CONV_DGRAD_S2: return dispatch_tile<ICK_OP_CONV_DGRAD_S2>(p, 4, st, d->tile);
-    case ICK_OP_CONV_WGRAD: return dispatch_tile<ICK_OP_CONV_WGRAD>(p, nz, st, d->tile);
-    default: return ick::fail(-1, "ick_gemm_f32: unknown op %d", d->op);
-  }
-}
-
 }  // namespace ickg

@@ -1,18 +1,37 @@
-// igemm_bf16_glds_impl.h — the bf16 / split-bf16 MFMA family with DIRECT global->LDS staging (LDS-DMA).
+// igemm_glds_impl.h — the MFMA implicit-GEMM family with DIRECT global->LDS staging (LDS-DMA, global_load_lds_dwordx4),
+// ONE source for all arithmetic variants (template parameter TERMS; one translation unit per value, see the *_glds*.hip
+// stubs): addressing, the DMA ring, the zero page, the LDS-staged epilogue, the chunked accumulation and the M-split
+// dispatch are shared; only the fragment reads and the MFMA differ.
+//   TERMS 0  exact fp32       v_mfma_f32_32x32x2_f32: one ds_read_b128 per 32x32 tile per 8 k (lane l reads
+//                              X[row l&31][8j + 4(l>>5) + 0..3]; MFMA e of the group multiplies k-slots {8j+e, 8j+4+e} —
+//                              the SAME pairing on both operands, so the sum is unchanged)
+//   TERMS 1  bf16             v_mfma_f32_32x32x16_bf16: two ds_read_b128 = 8 consecutive k per lane, rounded to bf16 IN
+//   TERMS 2  fp16             v_mfma_f32_32x32x16_f16   REGISTERS (the LDS images stay fp32: operands are fp32 in HBM)
+//   TERMS 3  split bf16       hi + lo parts in registers, hi*hi + hi*lo + lo*hi (~1e-5 of the fp32 product)
 //
-// Same DMA pipeline, LDS images (fp32!), zero page, buffering and epilogues as igemm_f32_glds.hip; only the compute
-// differs: fragments are read from the fp32 images (two ds_read_b128 = 8 consecutive k per lane for k-contiguous
-// operands, eight ds_read_b32 for x-contiguous ones), rounded to bf16 IN REGISTERS (v_cvt_pk_bf16_f32) and fed to
-// v_mfma_f32_32x32x16_bf16.  Why not the register-staged igemm_bf16.hip: at bf16 MFMA rates a k-tile is 256 matrix-pipe
-// cycles per wave while a global load takes ~2 us, so one register-staged tile of prefetch leaves the kernel
-// latency-bound (385 TF at 4096^3); the DMA ring keeps 1-2 whole tiles in flight per workgroup with no staging
-// registers and no conversion pass through the LDS write port.  TERMS == 3 splits each fp32 value into hi + lo bf16
-// parts in registers (hi*hi + hi*lo + lo*hi).
+// Why LDS-DMA: an ablation of the register-staged kernel (igemm_f32.hip; tools/ablate, profiles/r01g_ablation_f32.log) on
+// MI355X shows the MFMA loop alone runs at 142 TF (90 % of the fp32 MFMA peak) but the full kernel at 102 TF: issuing the
+// global loads + exposed load latency cost 18-25 % and the register->LDS write pass (ds_write, zero-masking VALU) another
+// 10-15 %.  LDS-DMA removes both: no staging VGPRs, no ds_write instructions, and a k-tile twice as deep (32) so that
+// one tile of prefetch covers the load latency.  At 16-bit MFMA rates a k-tile is 256 matrix-pipe cycles per wave while
+// a global load takes ~2 us: the DMA ring keeps 1-2 whole tiles in flight per workgroup (385 -> 417 TF at 4096^3).
+//
+//   C[z][m][n] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) + residual[m][n]        (same contract as igemm_f32.hip)
+//
+// LDS images (one LDS-DMA wave-instruction writes 64 lanes x 16 B = 1 KiB, lane-linear):
+//   * k-contiguous source: image [x][32 k] (128-B rows, 8 sixteen-byte chunks), chunk position XOR-swizzled by
+//     (row>>1)&7 THROUGH THE SOURCE ADDRESS (lane l of the DMA fetches the chunk that belongs at its linear slot).
+//     With the swizzle the four 16-lane groups of ds_read_b128 each touch 16 distinct 16-B slots: conflict-free.
+//   * x-contiguous source: image [32 k][x] (lane-linear as is), fragment = ds_read_b32 per k (32 consecutive floats).
+// Out-of-range elements (conv padding, M/N/K tails) are fetched from a 16-byte zero page instead of being masked
+// afterwards.  Two LDS buffers, one barrier per k-tile:  wait own DMA -> barrier -> issue DMA of tile t+1 -> MFMAs of t.
 #pragma once
 #include "igemm_params.h"
 #include <cstdlib>
 #include <type_traits>
-#define ICK_ABL 0
+#ifndef ICK_ABL
+#define ICK_ABL 0   // tools/ablate builds set 1..3 to price the epilogue and the DMA stream (never in libick.so)
+#endif
 
 namespace {
 
@@ -22,10 +41,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-// TERMS: 1 = bf16, 3 = split bf16, 2 = fp16 (v_mfma_f32_32x32x16_f16: the reference's autocast dtype, train_student_kd.py:271;
-// 10 mantissa bits instead of bf16's 7, but a 5-bit exponent: the caller runs it under the device-side GradScaler)
 template <int TERMS> struct Half16 { using x8 = bf16x8; };
-template <> struct Half16<2> { using x8 = f16x8; };
+template <> struct Half16<2> { using x8 = f16x8; };   // fp16: 10 mantissa bits, 5-bit exponent — run under the device GradScaler
 template <int TERMS, typename V>
 __device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
   if constexpr (TERMS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -36,7 +53,7 @@ constexpr int BK = 32;
 constexpr int NT = 256;
 
 __device__ __attribute__((aligned(16))) float g_zero16[4];   // the zero page
-const bool g_no_vec_epilogue = false;
+const bool g_no_vec_epilogue = [] { const char* e = getenv("ICK_NO_VEC_EPILOGUE"); return e && e[0] == '1'; }();   // A/B runs
 
 // One LDS-DMA wave-instruction: lane l's 16 bytes at `src` land at LDS byte address lds_wave_base + 16*l.
 // Issued through inline asm on purpose: hipcc tracks the builtin form as an LDS write on the VM counter and then
@@ -45,11 +62,14 @@ const bool g_no_vec_epilogue = false;
 // vmcnt wait that matters is the explicit one at the top of each iteration.
 __device__ __forceinline__ void glds16(const float* src, unsigned lds_wave_base) {
   const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_wave_base);
+#if ICK_ABL == 5   // timing experiment: every DMA is issued but fetches the zero page (issue cost without operand traffic)
+  src = g_zero16;
+#endif
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory");
 }
 
 template <int OP, int BM, int BN, int NBUF, int TERMS>
-__global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
+__global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(const P p) {
   constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int PA = BM / 32, PB = BN / 32;            // LDS-DMA instructions per thread per k-tile
@@ -64,7 +84,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
   const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;   // XCD-aware tile order (igemm_f32.hip)
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
   const int tile_m = wg / p.tiles_n, tile_n = wg - tile_m * p.tiles_n;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = p.m_base + tile_m * BM, n0 = tile_n * BN;   // m_base: first row of this launch (M-split dispatch)
 
   int z = blockIdx.z, split = 0;
   if (p.splitk > 1) { split = z; z = 0; }
@@ -246,9 +266,27 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
     }
   };
 
-  // fp32 fragment of MFMA k-step s (16 k): lane l holds X[row l&31][k = 16 s + 8 (l>>5) + 0..7]
+  // fragments of k-group j (8 k) of tile-row/column t: element e feeds MFMA e (k-slots {8j+e, 8j+4+e})
   const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
-  auto frag_a = [&](const float* Ab, int s, int i) -> f32x8 {
+  auto frag_a = [&](const float* Ab, int j, int i) -> float4 {
+    if constexpr (AK) {
+      return *reinterpret_cast<const float4*>(Ab + (wm * WM + i * 32 + frow) * BK + (((2 * j + fh) ^ fsw) << 2));
+    } else {
+      const float* q = Ab + (8 * j + 4 * fh) * BM + wm * WM + i * 32 + frow;
+      return make_float4(q[0], q[BM], q[2 * BM], q[3 * BM]);
+    }
+  };
+  auto frag_b = [&](const float* Bb, int j, int t) -> float4 {
+    if constexpr (BKc) {
+      return *reinterpret_cast<const float4*>(Bb + (wn * WN + t * 32 + frow) * BK + (((2 * j + fh) ^ fsw) << 2));
+    } else {
+      const float* q = Bb + (8 * j + 4 * fh) * BN + wn * WN + t * 32 + frow;
+      return make_float4(q[0], q[BN], q[2 * BN], q[3 * BN]);
+    }
+  };
+
+  // 16-bit variants: fp32 fragment of MFMA k-step s (16 k): lane l holds X[row l&31][k = 16 s + 8 (l>>5) + 0..7]
+  auto frag_a8 = [&](const float* Ab, int s, int i) -> f32x8 {
     if constexpr (AK) {
       const float* r = Ab + (wm * WM + i * 32 + frow) * BK;
       const float4 lo = *reinterpret_cast<const float4*>(r + (((4 * s + 2 * fh) ^ fsw) << 2));
@@ -259,7 +297,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
       return f32x8{q[0], q[BM], q[2 * BM], q[3 * BM], q[4 * BM], q[5 * BM], q[6 * BM], q[7 * BM]};
     }
   };
-  auto frag_b = [&](const float* Bb, int s, int t) -> f32x8 {
+  auto frag_b8 = [&](const float* Bb, int s, int t) -> f32x8 {
     if constexpr (BKc) {
       const float* r = Bb + (wn * WN + t * 32 + frow) * BK;
       const float4 lo = *reinterpret_cast<const float4*>(r + (((4 * s + 2 * fh) ^ fsw) << 2));
@@ -278,6 +316,22 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // Chunked accumulation: one MFMA accumulator is a strictly sequential fp32 chain over k, whose rounding error grows
+  // with the chain length (measured: a K = 4608 chain is 4x further from fp64 than a K-blocked CPU GEMM, and that excess
+  // shows up 1.5-3x in every gradient behind the ResNet trunk).  Every p.chunk_tiles k-tiles (64 k by default; CPU
+  // GEMMs block K at ~256) the chain is folded into a master sum and restarted from zero.  Measured on the KD step
+  // (tools/diag_grads.py, profiles/r02_diag_grads_B{2,8}.log, chunk 128): gradient error vs fp64 relative to torch's
+  // CPU fp32 falls from 4.3-4.5x (refinement / decoder, B = 8) to 0.98x, trunk 1.10x -> 0.92x; an isolated K = 2304
+  // data gradient goes from 1.8e-6 to 2.6e-7 of scale.  Cost: none measurable (29.83 vs 29.81 ms/step at chunk 64 / 128,
+  // 194.3 vs 195.1 us for the ViT fc1 GEMM with / without folding): the fold's VALU adds hide under other waves' MFMAs.
+  f32x16 tot[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
+  int chain = 0;
 
   // NBUF = 2: DMA of tile t+1 is issued at the top of iteration t (one compute phase to land).
   // NBUF = 3: DMA of tile t+2 is issued at the top of iteration t (two compute phases to land); the wait at the top of
@@ -299,44 +353,90 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
     const float* Ab = lds + cb * BUF;
     cb = cb + 1 == NBUF ? 0 : cb + 1;
     const float* Bb = Ab + A_SZ;
-    f32x8 av[2][TM], bv[2][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) av[0][i] = frag_a(Ab, 0, i);
-#pragma unroll
-    for (int t = 0; t < TN; ++t) bv[0][t] = frag_b(Bb, 0, t);
-#pragma unroll
-    for (int s = 0; s < BK / 16; ++s) {
-      const int cur = s & 1, nxt = cur ^ 1;
-      if (s + 1 < BK / 16) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) av[nxt][i] = frag_a(Ab, s + 1, i);
-#pragma unroll
-        for (int t = 0; t < TN; ++t) bv[nxt][t] = frag_b(Bb, s + 1, t);
+    if constexpr (TERMS == 0) {
+      float4 av[2][TM], bv[2][TN];
+  #pragma unroll
+      for (int i = 0; i < TM; ++i) av[0][i] = frag_a(Ab, 0, i);
+  #pragma unroll
+      for (int t = 0; t < TN; ++t) bv[0][t] = frag_b(Bb, 0, t);
+  #pragma unroll
+      for (int j = 0; j < BK / 8; ++j) {
+        const int cur = j & 1, nxt = cur ^ 1;
+        if (j + 1 < BK / 8) {
+  #pragma unroll
+          for (int i = 0; i < TM; ++i) av[nxt][i] = frag_a(Ab, j + 1, i);
+  #pragma unroll
+          for (int t = 0; t < TN; ++t) bv[nxt][t] = frag_b(Bb, j + 1, t);
+        }
+        // keep the next group's LDS reads AHEAD of this group's MFMAs (hipcc otherwise sinks them behind the MFMAs and
+        // exposes the LDS latency at the head of every group)
+        __builtin_amdgcn_sched_barrier(0);
+  #pragma unroll
+        for (int i = 0; i < TM; ++i)
+  #pragma unroll
+          for (int t = 0; t < TN; ++t) {
+            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].x, bv[cur][t].x, acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].y, bv[cur][t].y, acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].z, bv[cur][t].z, acc[i][t], 0, 0, 0);
+            acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].w, bv[cur][t].w, acc[i][t], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      using h8 = typename Half16<TERMS>::x8;
-      h8 ah[TM], bh[TN], al[TM], bl[TN];
+    } else {
+      f32x8 av[2][TM], bv[2][TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = __builtin_convertvector(av[cur][i], h8);
-        if constexpr (TERMS == 3) al[i] = __builtin_convertvector(av[cur][i] - __builtin_convertvector(ah[i], f32x8), h8);
-      }
+      for (int i = 0; i < TM; ++i) av[0][i] = frag_a8(Ab, 0, i);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) {
-        bh[t] = __builtin_convertvector(bv[cur][t], h8);
-        if constexpr (TERMS == 3) bl[t] = __builtin_convertvector(bv[cur][t] - __builtin_convertvector(bh[t], f32x8), h8);
+      for (int t = 0; t < TN; ++t) bv[0][t] = frag_b8(Bb, 0, t);
+#pragma unroll
+      for (int s = 0; s < BK / 16; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < BK / 16) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) av[nxt][i] = frag_a8(Ab, s + 1, i);
+#pragma unroll
+          for (int t = 0; t < TN; ++t) bv[nxt][t] = frag_b8(Bb, s + 1, t);
+        }
+        using h8 = typename Half16<TERMS>::x8;
+        h8 ah[TM], bh[TN], al[TM], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          ah[i] = __builtin_convertvector(av[cur][i], h8);
+          if constexpr (TERMS == 3) al[i] = __builtin_convertvector(av[cur][i] - __builtin_convertvector(ah[i], f32x8), h8);
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          bh[t] = __builtin_convertvector(bv[cur][t], h8);
+          if constexpr (TERMS == 3) bl[t] = __builtin_convertvector(bv[cur][t] - __builtin_convertvector(bh[t], f32x8), h8);
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int t = 0; t < TN; ++t) {
+            if constexpr (TERMS == 3) {   // small terms first
+              acc[i][t] = mfma16<TERMS>(al[i], bh[t], acc[i][t]);
+              acc[i][t] = mfma16<TERMS>(ah[i], bl[t], acc[i][t]);
+            }
+            acc[i][t] = mfma16<TERMS>(ah[i], bh[t], acc[i][t]);
+          }
       }
+    }
+    if (TERMS == 0 && ++chain == p.chunk_tiles && kt + 1 < nkt) {   // (16-bit products: operand rounding dominates the chain's)
+      chain = 0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
-          if constexpr (TERMS == 3) {   // small terms first
-            acc[i][t] = mfma16<TERMS>(al[i], bh[t], acc[i][t]);
-            acc[i][t] = mfma16<TERMS>(ah[i], bl[t], acc[i][t]);
-          }
-          acc[i][t] = mfma16<TERMS>(ah[i], bh[t], acc[i][t]);
+          tot[i][t] += acc[i][t];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
         }
     }
   }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t];
 
   // ---------------------------------------------------------------- epilogue
   // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -422,7 +522,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mb + (r & 3) + 8 * (r >> 2);
-          if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL == 4 || alpha == 12345.f)) {
+          if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL >= 4 || alpha == 12345.f)) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq = fmaf(v, v, ssq);
             v = act_fn(v + bias, act);
@@ -439,7 +539,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
           }
         }
       }
-      if (p.stat_sum && (ICK_ABL < 1 || ICK_ABL == 4 || alpha == 12345.f)) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
+      if (p.stat_sum && (ICK_ABL < 1 || ICK_ABL >= 4 || alpha == 12345.f)) {  // BatchNorm batch statistics of the raw product; fp64 so that E[x^2]-E[x]^2 cannot cancel
         ssum += __shfl_xor(ssum, 32);
         ssq += __shfl_xor(ssq, 32);
         if (lane < 32 && nok) {
@@ -457,52 +557,93 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_glds_kernel(const P p) {
   else epilogue(std::false_type{});
 }
 
+// rows [m_begin, m_end) of the problem (m_end <= 0: all of M).  A launch over a row range is what the M-split dispatch
+// uses: bounds are checked against p.M = m_end, addresses are formed from the global row index.
 template <int OP, int BM, int BN, int NBUF, int TERMS>
-int launch(const P& p0, int nz, hipStream_t st) {
+int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) {
   P p = p0;
+  if (m_end <= 0 || m_end > p.M) m_end = p.M;
+  p.m_base = m_begin;
+  p.M = m_end;
   p.tiles_n = (p.N + BN - 1) / BN;
   // 16-byte stores need every row start of C (and of the residual) 16-byte aligned
   p.ep_vec = p.N % 4 == 0 && p.ldc % 4 == 0 && (p.sCo | p.sCi) % 4 == 0 && ick::aligned16(p.C) &&
              (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual))) && !g_no_vec_epilogue && !p.no_ep_vec;
   if ((p.col_scale || (p.act & ICK_ACT_POST_RESIDUAL)) && !(p.ep_vec && p.splitk == 1))
     return ick::fail(-1, "igemm: col_scale / ICK_ACT_POST_RESIDUAL need 16-byte aligned C rows (N %% 4, ldc %% 4) and no split-K");
-  dim3 grid(p.tiles_n * ((p.M + BM - 1) / BM), 1, nz);
-  ICK_LAUNCH((igemm_bf16_glds_kernel<OP, BM, BN, NBUF, TERMS>), grid, dim3(NT), 0, st, p);
-  return ick::launch_status("igemm_bf16_glds");
+  dim3 grid(p.tiles_n * ((p.M - m_begin + BM - 1) / BM), 1, nz);
+  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS>), grid, dim3(NT), 0, st, p);
+  return ick::launch_status("igemm_glds");
+}
+
+constexpr int kCUs = 256;            // MI355X
+constexpr int kBodySlots = 2 * kCUs; // 128x128 workgroups resident at once (64 KiB of LDS each: two per CU)
+
+template <int OP, int TERMS>
+int launch_tile(const P& p, int nz, hipStream_t st, int tile, int m_begin = 0, int m_end = 0) {
+  switch (tile) {           // +16: three LDS buffers (two tiles of prefetch) instead of two
+    case 2: return launch<OP, 64, 64, 2, TERMS>(p, nz, st, m_begin, m_end);
+    case 3: return launch<OP, 128, 64, 2, TERMS>(p, nz, st, m_begin, m_end);
+    case 4: return launch<OP, 64, 128, 2, TERMS>(p, nz, st, m_begin, m_end);
+    case 18: return launch<OP, 64, 64, 3, TERMS>(p, nz, st, m_begin, m_end);
+    case 19: return launch<OP, 128, 64, 3, TERMS>(p, nz, st, m_begin, m_end);
+    case 20: return launch<OP, 64, 128, 3, TERMS>(p, nz, st, m_begin, m_end);
+    default: return launch<OP, 128, 128, 2, TERMS>(p, nz, st, m_begin, m_end);
+  }
+}
+
+// M-split (IckGemm.tile +32): the 128x128 tile is the family's most efficient at long K (half the operand stream per FLOP
+// of the 64x64 one: 119-127 TF against ~80 at 4096^3) but a grid of T such workgroups runs in ceil(T / 512) rounds, and
+// the step's shapes leave the last round mostly empty (ViT: M = 12608 -> 2.32 rounds).  So: the rows that fill WHOLE
+// rounds go to the 128x128 kernel, the remaining rows to a second launch with a small tile whose own partial round is
+// short.  Measured (profiles/r02b_step_gemm_shapes_tile_sweep.log): a wash on the step's short-K shapes — the ViT fc1
+// GEMM takes 177 us split vs 175 (128x128 alone) vs 166-169 (64-row tiles): with K = 384 a 128x128 workgroup spends as
+// long in its prologue + GELU epilogue as two of its twelve k-tiles, and only two of them share a CU — it wins 2-3 % on
+// the K >= 512 Linear shapes (fc2, teacher decoder).  Kept as a tuned-table option, not chosen by the cost model.
+// Returns the first row of the tail (0: no full round exists -> everything is tail; M: no tail).
+inline int msplit_row(const P& p, int nz) {
+  if (nz != 1) return 0;
+  const long tiles_n = (p.N + 127) / 128, tiles_m = (p.M + 127) / 128;
+  const long rounds = tiles_m * tiles_n / kBodySlots;
+  long rows = rounds * kBodySlots / tiles_n;                 // tile rows of the body
+  if (rows >= tiles_m) return p.M;
+  return (int)(rows * 128);
 }
 
 template <int OP, int TERMS>
 int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
+  static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
+  static const double eff[4] = {1.00, 0.85, 0.93, 0.93};   // relative efficiency of the tile shape
+  bool split = (tile & 32) != 0;
+  tile &= 31;
   if (tile == 0) {
-    static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
-    static const double eff[4] = {1.00, 0.85, 0.93, 0.93};   // relative efficiency of the tile shape
     double best = 1e300;
+    auto cost_of = [&](int t, long rows) {                   // busiest CU's share of tile area / efficiency
+      const long blocks = ((rows + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * nz;
+      return (double)((blocks + kCUs - 1) / kCUs) * bm[t] * bn[t] / eff[t];
+    };
     for (int t = 0; t < 4; ++t) {
-      const long blocks = (long)((p.M + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * nz;
-      const long per_cu = (blocks + 255) / 256;
-      const double cost = (double)per_cu * bm[t] * bn[t] / eff[t];
+      const double cost = cost_of(t, p.M);
       if (cost < best * 0.999) { best = cost; tile = t + 1; }
     }
   }
-  switch (tile) {           // +16: three LDS buffers (two tiles of prefetch) instead of two
-    case 2: return launch<OP, 64, 64, 2, TERMS>(p, nz, st);
-    case 3: return launch<OP, 128, 64, 2, TERMS>(p, nz, st);
-    case 4: return launch<OP, 64, 128, 2, TERMS>(p, nz, st);
-    case 18: return launch<OP, 64, 64, 3, TERMS>(p, nz, st);
-    case 19: return launch<OP, 128, 64, 3, TERMS>(p, nz, st);
-    case 20: return launch<OP, 64, 128, 3, TERMS>(p, nz, st);
-    default: return launch<OP, 128, 128, 2, TERMS>(p, nz, st);
+  if (split && OP != ICK_OP_CONV_DGRAD_S2) {
+    const int ms = msplit_row(p, nz);
+    if (ms >= p.M) return launch<OP, 128, 128, 2, TERMS>(p, nz, st);
+    if (ms > 0) {
+      if (int rc = launch<OP, 128, 128, 2, TERMS>(p, nz, st, 0, ms)) return rc;
+      return launch_tile<OP, TERMS>(p, nz, st, tile, ms, p.M);
+    }
   }
+  return launch_tile<OP, TERMS>(p, nz, st, tile);
 }
 
 }  // namespace
 
 namespace ickg {
-
-// one translation unit per TERMS value (igemm_bf16_glds_t1.hip / _t3.hip): the 49 kernel instantiations of each compile
-// in parallel instead of 98 in one 2.5-minute hipcc run
-int ICK_BF16_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
-  constexpr int TERMS = ICK_BF16_GLDS_TERMS;
+// argument checks are done by the caller; p/nz come from prepare(d, 32, ...); eligibility = glds_eligible(d)
+int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
+  constexpr int TERMS = ICK_GLDS_TERMS;
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
     case ICK_OP_NN: return dispatch_tile<ICK_OP_NN, TERMS>(p, nz, st, d->tile);
@@ -511,8 +652,10 @@ int ICK_BF16_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
     case ICK_OP_CONV_FWD_C4: return dispatch_tile<ICK_OP_CONV_FWD_C4, TERMS>(p, nz, st, d->tile);
     case ICK_OP_CONV_DGRAD: return dispatch_tile<ICK_OP_CONV_DGRAD, TERMS>(p, nz, st, d->tile);
     case ICK_OP_CONV_DGRAD_S2: return dispatch_tile<ICK_OP_CONV_DGRAD_S2, TERMS>(p, 4, st, d->tile);
-    default: return ick::fail(-1, "ick_gemm_bf16: op %d has no LDS-DMA variant", d->op);
+    case ICK_OP_CONV_WGRAD:
+      if constexpr (TERMS == 0) return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS>(p, nz, st, d->tile);
+      else return ick::fail(-1, "ick_gemm_bf16: op %d has no LDS-DMA variant", d->op);
+    default: return ick::fail(-1, "igemm (LDS-DMA): unknown op %d", d->op);
   }
 }
-
 }  // namespace ickg
