@@ -113,6 +113,23 @@ def test_state_dict_surface_matches_reference_on_cpu():
     assert s.encoder.resnet[6][0].conv2.weight.is_contiguous(memory_format=torch.channels_last)
 
 
+def test_compact_student_surface_matches_reference_on_cpu():
+    """N4: CompactCaptioningStudent keeps the reference's state_dict keys, parameter counts and frozen set (captured from the
+    reference class in tests/golden/compact_student.npz) — parameter holders only, no compute on the CPU."""
+    import numpy as np
+    from conftest import load_golden
+    from imagecaptioner_amd.student_model_compact import CompactCaptioningStudent, count_parameters
+    g = load_golden("compact_student.npz")
+    m = CompactCaptioningStudent(5000, 256, 256, 1)
+    assert sorted(m.state_dict().keys()) == sorted(g["keys"].tolist())
+    assert count_parameters(m) == (int(g["total_params"]), int(g["trainable_params"]))
+    frozen = [k for k, p in m.named_parameters() if not p.requires_grad]
+    assert frozen and all(int(k.split(".")[2]) < 10 for k in frozen)          # features[0:10] (student_model_compact.py:26-30)
+    assert m.encoder.adaptive_pool.output_size == (7, 7) and m.decoder.lstm.weight_hh_l0.shape == (1024, 256)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 3, 224, 224), torch.zeros(3, 1, dtype=torch.long))   # no CPU fallback
+
+
 def test_create_feature_projectors_and_helpers():
     from imagecaptioner_amd import distillation_utils as D
     from imagecaptioner_amd.student_model import CaptioningStudent
