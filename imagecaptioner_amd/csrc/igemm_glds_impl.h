@@ -50,7 +50,6 @@ __device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
 }
 
 constexpr int BK = 32;
-constexpr int NT = 256;
 
 __device__ __attribute__((aligned(16))) float g_zero16[4];   // the zero page
 const bool g_no_vec_epilogue = [] { const char* e = getenv("ICK_NO_VEC_EPILOGUE"); return e && e[0] == '1'; }();   // A/B runs
@@ -68,11 +67,15 @@ __device__ __forceinline__ void glds16(const float* src, unsigned lds_wave_base)
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(m0v) : "memory");
 }
 
-template <int OP, int BM, int BN, int NBUF, int TERMS>
-__global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(const P p) {
+// NW = waves per workgroup: 4 (2 x 2 wave grid) or 8 (4 x 2, BM = 128 only: twice the waves per SIMD behind the same LDS
+// footprint — the 128-row tiles otherwise leave 2-3 waves per SIMD to cover the per-k-tile barrier and the epilogues)
+template <int OP, int BM, int BN, int NBUF, int TERMS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
   constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
-  constexpr int PA = BM / 32, PB = BN / 32;            // LDS-DMA instructions per thread per k-tile
+  constexpr int NT = NW * 64;
+  constexpr int WM = BM / (NW / 2), WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  static_assert(WM >= 32 && WN >= 32, "a wave owns at least one 32x32 MFMA tile");
+  constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);   // LDS-DMA instructions per thread per k-tile
   constexpr int A_SZ = BM * BK, B_SZ = BN * BK, BUF = A_SZ + B_SZ;
   constexpr int A_TPK = BM / 4, B_TPK = BN / 4;        // lanes per k-row of an x-contiguous image
   constexpr int A_RPI = 64 / A_TPK, B_RPI = 64 / B_TPK;  // k-rows per DMA instruction (x-contiguous)
@@ -559,7 +562,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_glds_kernel(const P p) {
 
 // rows [m_begin, m_end) of the problem (m_end <= 0: all of M).  A launch over a row range is what the M-split dispatch
 // uses: bounds are checked against p.M = m_end, addresses are formed from the global row index.
-template <int OP, int BM, int BN, int NBUF, int TERMS>
+template <int OP, int BM, int BN, int NBUF, int TERMS, int NW = 4>
 int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) {
   P p = p0;
   if (m_end <= 0 || m_end > p.M) m_end = p.M;
@@ -572,7 +575,7 @@ int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) 
   if ((p.col_scale || (p.act & ICK_ACT_POST_RESIDUAL)) && !(p.ep_vec && p.splitk == 1))
     return ick::fail(-1, "igemm: col_scale / ICK_ACT_POST_RESIDUAL need 16-byte aligned C rows (N %% 4, ldc %% 4) and no split-K");
   dim3 grid(p.tiles_n * ((p.M - m_begin + BM - 1) / BM), 1, nz);
-  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS>), grid, dim3(NT), 0, st, p);
+  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>), grid, dim3(NW * 64), 0, st, p);
   return ick::launch_status("igemm_glds");
 }
 
@@ -588,6 +591,9 @@ int launch_tile(const P& p, int nz, hipStream_t st, int tile, int m_begin = 0, i
     case 18: return launch<OP, 64, 64, 3, TERMS>(p, nz, st, m_begin, m_end);
     case 19: return launch<OP, 128, 64, 3, TERMS>(p, nz, st, m_begin, m_end);
     case 20: return launch<OP, 64, 128, 3, TERMS>(p, nz, st, m_begin, m_end);
+    case 65: return launch<OP, 128, 128, 2, TERMS, 8>(p, nz, st, m_begin, m_end);     // +64: eight waves per workgroup
+    case 67: return launch<OP, 128, 64, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
+    case 83: return launch<OP, 128, 64, 3, TERMS, 8>(p, nz, st, m_begin, m_end);
     default: return launch<OP, 128, 128, 2, TERMS>(p, nz, st, m_begin, m_end);
   }
 }
@@ -615,8 +621,8 @@ int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
   static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
   static const double eff[4] = {1.00, 0.85, 0.93, 0.93};   // relative efficiency of the tile shape
   bool split = (tile & 32) != 0;
-  tile &= 31;
-  if (tile == 0) {
+  tile &= 64 | 31;
+  if ((tile & 31) == 0) {
     double best = 1e300;
     auto cost_of = [&](int t, long rows) {                   // busiest CU's share of tile area / efficiency
       const long blocks = ((rows + bm[t] - 1) / bm[t]) * ((p.N + bn[t] - 1) / bn[t]) * nz;

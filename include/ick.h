@@ -69,7 +69,7 @@ typedef struct IckGemm {
   float alpha;
   /* convolution geometry (ICK_OP_CONV_*): X [Nb][H][W][Cin], Y [Nb][Ho][Wo][Cout] */
   int32_t Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad;
-  int32_t tile;                                 /* 0 = choose by the wave-quantisation model; 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128; +16 = three LDS buffers (LDS-DMA kernel); +32 = M-split: 128x128 workgroups for the rows that fill whole rounds of the chip, the tile named by the low bits for the remaining rows (two launches); +256 = register-staged kernel */
+  int32_t tile;                                 /* 0 = choose by the wave-quantisation model; 1 = 128x128, 2 = 64x64, 3 = 128x64, 4 = 64x128; +16 = three LDS buffers (LDS-DMA kernel); +64 = eight waves per workgroup (LDS-DMA kernel, 128-row tiles: 65, 67, 83); +32 = M-split: 128x128 workgroups for the rows that fill whole rounds of the chip, the tile named by the low bits for the remaining rows (two launches); +256 = register-staged kernel */
   int32_t stat_copies;                          /* <= 1: one accumulator row; R > 1: stat_sum/stat_sq are [R][stat_stride] and the row-tile t of the grid adds into copy t % R (spreads the fp64 atomics of large-M convolutions over R x as many cache lines; consumers sum the copies) */
   int64_t stat_stride;                          /* elements between two copies (>= N) */
   const float* col_scale;                       /* [N] or NULL: C = act(col_scale[n] * alpha*sum + bias[n] ...) — eval-mode BatchNorm folded into the conv epilogue (scale = gamma/sqrt(var+eps), bias = shift); needs N %% 4, ldc %% 4, no split-K */

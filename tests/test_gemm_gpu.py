@@ -161,7 +161,7 @@ def test_conv_stem_c4(ops):
     assert torch.equal(mp.permute(0, 3, 1, 2).cpu(), F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 3, 2, 1))
 
 
-@pytest.mark.parametrize("tile", [34, 35, 36, 50, 0])
+@pytest.mark.parametrize("tile", [34, 35, 36, 50, 0, 65, 67, 83, 65 + 32])
 def test_msplit_dispatch_linear_and_conv_vs_fp64(tile):
     """IckGemm.tile +32: rows that fill whole rounds of the chip run on 128x128 workgroups, the remaining rows in a second
     launch with a smaller tile (tile 0 lets the library's cost model decide).  Both launches must cover every row exactly
@@ -232,3 +232,37 @@ def test_full_size_step_shapes_with_their_tuned_tiles_vs_fp64():
     xb, wb, bb, rb = rnd(B * 197, 1536, seed=9), rnd(384, 1536, seed=10, scale=0.03), rnd(384, seed=11), rnd(B * 197, 384, seed=12)
     yb = o.linear_fwd(xb.cuda(), wb.cuda(), bb.cuda(), residual=rb.cuda())
     assert rel_err(yb, xb.double() @ wb.double().T + bb.double() + rb.double()) < 2e-5
+
+
+@pytest.mark.parametrize("tile", [65, 67, 83])
+def test_eight_wave_tiles_all_ops_vs_fp64(tile):
+    """IckGemm.tile +64: the 128-row tiles with eight waves per workgroup (4 x 2 wave grid) — every operand-fetch pattern of
+    the LDS-DMA kernel (k-contiguous / x-contiguous A and B, conv gathers, stride-2 parity classes) against float64."""
+    from imagecaptioner_amd import ops as o
+    o._FORCE_TILE[0] = tile
+    try:
+        M, N, K = 300, 200, 136
+        x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(M, N, seed=3)
+        assert rel_err(o.linear_fwd(x.cuda(), w.cuda()), x.double() @ w.double().T) < 2e-5                 # NT
+        assert rel_err(o.linear_bwd_data(dy.cuda(), w.cuda()), dy.double() @ w.double()) < 2e-5             # NN
+        dw = torch.zeros(N, K, device="cuda")
+        o.linear_bwd_weight(dy.cuda(), x.cuda(), dw, splitk=1)
+        assert rel_err(dw, dy.double().T @ x.double()) < 2e-5                                                # TN
+        xc, wc = rnd(3, 14, 14, 64, seed=4), rnd(96, 3, 3, 64, seed=5, scale=0.1)
+        xr, wr = xc.double().permute(0, 3, 1, 2), wc.double().permute(0, 3, 1, 2)
+        for stride in (1, 2):
+            ref = F.conv2d(xr, wr, stride=stride, padding=1)
+            y = o.conv_fwd(xc.cuda(), wc.cuda(), stride, 1)
+            assert rel_err(y.permute(0, 3, 1, 2), ref) < 2e-5                                                # CONV_FWD
+            dyc = rnd(*y.shape, seed=6)
+            dx = o.conv_dgrad(dyc.cuda(), wc.cuda(), (14, 14), stride, 1)
+            refdx = torch.nn.grad.conv2d_input(xr.shape, wr, dyc.double().permute(0, 3, 1, 2), stride=stride, padding=1)
+            assert rel_err(dx.permute(0, 3, 1, 2), refdx) < 2e-5                                             # dgrad (as fwd / S2 classes)
+        o._DGRAD_AS_FWD[0] = False
+        dyc = rnd(3, 14, 14, 96, seed=7)
+        dx = o.conv_dgrad(dyc.cuda(), wc.cuda(), (14, 14), 1, 1)
+        refdx = torch.nn.grad.conv2d_input(xr.shape, wr, dyc.double().permute(0, 3, 1, 2), padding=1)
+        assert rel_err(dx.permute(0, 3, 1, 2), refdx) < 2e-5                                                 # CONV_DGRAD gather kernel
+    finally:
+        o._FORCE_TILE[0] = 0
+        o._DGRAD_AS_FWD[0] = True

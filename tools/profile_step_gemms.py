@@ -63,8 +63,8 @@ out = torch.empty(1 << 27, device="cuda")
 stat = torch.zeros(2, 4096, dtype=torch.float64, device="cuda")
 rows = []
 TN_ = ["model", "128x128", "64x64", "128x64", "64x128", "3b64x64", "3b128x64", "3b64x128", "r128x128", "r64x64", "r128x64", "r64x128",
-       "s+64x64", "s+128x64", "s+64x128", "s+3b64x64"]
-TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260, 34, 35, 36, 50]   # +16: three LDS buffers; +32: M-split (128x128 body + that tail tile); +256: the register-staged kernel
+       "s+64x64", "s+128x64", "s+64x128", "s+3b64x64", "8w128x128", "8w128x64", "8w3b128x64"]
+TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260, 34, 35, 36, 50, 65, 67, 83]   # +16: three LDS buffers; +32: M-split (128x128 body + that tail tile); +256: the register-staged kernel
 if PREC != "f32":
     ops.set_gemm_precision(PREC)
 
