@@ -211,8 +211,9 @@ def dominant_kernel(dev, iters=20):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / iters * 1e3
     tf = 2.0 * M * N * K / us / 1e6
+    tid = ops._TUNED.get(f"0:{M}:{N}:{K}:1:1", 0)
     tile = {1: "128,128", 2: "64,64", 3: "128,64", 4: "64,128", 18: "64,64,3buf", 19: "128,64,3buf", 20: "64,128,3buf"}.get(
-        ops._TUNED.get(f"0:{M}:{N}:{K}:1:1", 0) & 31, "cost-model tile")
+        tid & 31, "cost-model tile") + (",8 waves" if tid & 64 else "") + (",M-split" if tid & 32 else "")
     return {"kernel": f"igemm_f32_glds_kernel<NT,{tile}> ViT fc1 Linear+GELU 12608x1536x384 (fp32 MFMA, LDS-DMA staging, chunked accumulation)",
             "avg_us": round(us, 1), "achieved": round(tf, 1), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F32_MFMA_TF, 4)}
