@@ -384,7 +384,7 @@ def test_staged_data_parallel_step_under_an_rccl_group_equals_single_graph_step(
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
-def test_two_rank_rccl_step_matches_serial_average():
+def test_two_rank_rccl_step_matches_serial_average(tmp_path):
     """world 2 over RCCL: after one staged step both ranks hold identical parameters, and the all-reduced gradient equals
     the sum of the two ranks' own gradients (recomputed serially on rank 0)."""
     import subprocess
@@ -406,10 +406,13 @@ def test_two_rank_rccl_step_matches_serial_average():
         "dist.all_gather(both, chk)\n"
         "assert float((both[0] - both[1]).abs()) == 0.0, both\n"
         "dist.destroy_process_group(); print('ranks agree')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_rank_step.py"
+    script.write_text(f"import sys; sys.path.insert(0, {root!r})\n" + code)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), "-c", code], env=env, capture_output=True, text=True,
-                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+                        "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True,
+                       cwd=root, timeout=600)
     assert r.returncode == 0 and "ranks agree" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
