@@ -8,6 +8,11 @@
 //   TERMS 1  bf16             v_mfma_f32_32x32x16_bf16: two ds_read_b128 = 8 consecutive k per lane, rounded to bf16 IN
 //   TERMS 2  fp16             v_mfma_f32_32x32x16_f16   REGISTERS (the LDS images stay fp32: operands are fp32 in HBM)
 //   TERMS 3  split bf16       hi + lo parts in registers, hi*hi + hi*lo + lo*hi (~1e-5 of the fp32 product)
+//   TERMS 5 / 6  NATIVE bf16 / fp16 operands: A and B are 16-bit in HBM and in LDS.  The kernel addresses them in
+//                              "units" of two halves (the host halves K, lda, ldb, Cin), so every line of addressing / DMA /
+//                              swizzle code is the fp32 one; the fp32-style fragment (ds_read_b128 = 4 units) IS the 8
+//                              consecutive k a lane feeds to v_mfma_f32_32x32x16_*: one MFMA per fragment, no conversion,
+//                              half the L2->LDS stream of TERMS 1 / 2.  k-contiguous operands only (NT, CONV_FWD).
 //
 // Why LDS-DMA: an ablation of the register-staged kernel (igemm_f32.hip; tools/ablate, profiles/r01g_ablation_f32.log) on
 // MI355X shows the MFMA loop alone runs at 142 TF (90 % of the fp32 MFMA peak) but the full kernel at 102 TF: issuing the
@@ -43,9 +48,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int TERMS> struct Half16 { using x8 = bf16x8; };
 template <> struct Half16<2> { using x8 = f16x8; };   // fp16: 10 mantissa bits, 5-bit exponent — run under the device GradScaler
+template <> struct Half16<6> { using x8 = f16x8; };
 template <int TERMS, typename V>
 __device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
-  if constexpr (TERMS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  if constexpr (TERMS == 2 || TERMS == 6) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
     const float* Ab = lds + cb * BUF;
     cb = cb + 1 == NBUF ? 0 : cb + 1;
     const float* Bb = Ab + A_SZ;
-    if constexpr (TERMS == 0) {
+    if constexpr (TERMS == 0 || TERMS >= 5) {
       float4 av[2][TM], bv[2][TN];
   #pragma unroll
       for (int i = 0; i < TM; ++i) av[0][i] = frag_a(Ab, 0, i);
@@ -378,6 +384,11 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
         for (int i = 0; i < TM; ++i)
   #pragma unroll
           for (int t = 0; t < TN; ++t) {
+            if constexpr (TERMS >= 5) {      // native 16-bit operands: the four units ARE the lane's eight halves
+              using h8 = typename Half16<TERMS>::x8;
+              acc[i][t] = mfma16<TERMS>(__builtin_bit_cast(h8, av[cur][i]), __builtin_bit_cast(h8, bv[cur][t]), acc[i][t]);
+              continue;
+            }
             acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].x, bv[cur][t].x, acc[i][t], 0, 0, 0);
             acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].y, bv[cur][t].y, acc[i][t], 0, 0, 0);
             acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].z, bv[cur][t].z, acc[i][t], 0, 0, 0);
@@ -650,6 +661,8 @@ namespace ickg {
 // argument checks are done by the caller; p/nz come from prepare(d, 32, ...); eligibility = glds_eligible(d)
 int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
   constexpr int TERMS = ICK_GLDS_TERMS;
+  if constexpr (TERMS >= 5)
+    if (d->op != ICK_OP_NT && d->op != ICK_OP_CONV_FWD) return ick::fail(-1, "igemm (native 16-bit): k-contiguous operands only (NT, CONV_FWD), got op %d", d->op);
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
     case ICK_OP_NN: return dispatch_tile<ICK_OP_NN, TERMS>(p, nz, st, d->tile);

@@ -130,6 +130,37 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
     check(_lib.lib().ick_gemm_f32(ctypes.byref(d), _st()), "ick_gemm_f32")
 
 
+def cast16(x: torch.Tensor, fp16: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fp32 -> bf16 / fp16 copy (round to nearest even) for the native 16-bit GEMM operands."""
+    _chk(x, "x")
+    assert x.is_contiguous() and x.numel() % 4 == 0
+    y = out if out is not None else torch.empty(x.shape, dtype=torch.float16 if fp16 else torch.bfloat16, device=x.device)
+    check(_lib.lib().ick_cast_f32_to_16(x.data_ptr(), y.data_ptr(), x.numel(), int(fp16), _st()), "ick_cast_f32_to_16")
+    return y
+
+
+def gemm_h16_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, fp16: bool = False,
+                 bias: Optional[int] = None, residual: Optional[int] = None, ldr: int = 0, act: int = ACT_NONE,
+                 alpha: float = 1.0, accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
+                 conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0,
+                 col_scale: Optional[int] = None) -> None:
+    """C (fp32) = epilogue(A @ B^T) with A, B stored as bf16 / fp16 (ick_gemm_h16: OP_NT and OP_CONV_FWD)."""
+    d = IckGemm()
+    d.A, d.B, d.C = A, B, C
+    d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
+    d.stat_copies, d.stat_stride = stat_copies, stat_stride
+    d.col_scale = col_scale
+    d.op, d.act = op, act
+    d.M, d.N, d.K = M, N, K
+    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
+    d.batch_outer, d.batch_inner = 1, 1
+    d.splitk, d.accumulate, d.alpha = 1, int(accumulate), alpha
+    if conv is not None:
+        d.Nb, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.R, d.S, d.stride, d.pad = conv
+    d.tile = tile or _FORCE_TILE[0]
+    check(_lib.lib().ick_gemm_h16(ctypes.byref(d), int(fp16), _st()), "ick_gemm_h16")
+
+
 # ----------------------------------------------------------------------------- Linear
 def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:

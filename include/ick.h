@@ -86,6 +86,12 @@ int ick_gemm_f32(const IckGemm* desc, void* stream);
  * hi*hi + hi*lo + lo*hi accumulated (~1e-5 relative to the exact fp32 product, 3 MFMAs per k-step).
  * Convolutions whose channel count is not a multiple of 32 run on the exact-fp32 kernel. */
 int ick_gemm_bf16(const IckGemm* desc, int terms, void* stream);
+/* NATIVE 16-bit operands: A [M][K] and B [N][K] hold bf16 (fp16 = 0) or fp16 (fp16 = 1) elements in HBM — the storage the
+ * reference's autocast keeps (train_student_kd.py:271); fp32 accumulation, fp32 C and epilogues as above.  ICK_OP_NT and
+ * ICK_OP_CONV_FWD only (both operands k-contiguous); M, N, K, lda, ldb and the conv geometry are in ELEMENTS; K, lda, ldb
+ * multiples of 8, Cin a multiple of 64; no batching / split-K.  ick_cast_f32_to_16 produces such operands (n % 4 == 0). */
+int ick_gemm_h16(const IckGemm* desc, int fp16, void* stream);
+int ick_cast_f32_to_16(const float* x, void* y, int64_t n, int fp16, void* stream);
 
 /* ------------------------------------------------------------------ fused attention forward (head dim 64)
  * softmax(Q K^T * scale [causal]) V per (batch, head) without materialising the scores: timm ViT-S/16 self-attention
