@@ -21,6 +21,11 @@
 //     conflict-free per 32-lane half.
 // Global->LDS is register-staged (the fp32->bf16 rounding has to happen in flight): tile t+1's loads are issued
 // before tile t's MFMAs and written to the other LDS buffer after them; one barrier per k-tile.
+//
+// IN16 instantiations (ick_gemm_h16): A and B already hold bf16 / fp16 elements in HBM.  Same thread -> element map
+// (4 elements per fetch, now 8 bytes), no rounding in flight; C and the residual may be 16-bit too (P.c16 / P.r16).  This is
+// the kernel of the 16-bit training regime for the products whose operands are NOT k-contiguous (weight gradients,
+// stride-2 data gradients); k-contiguous ones take the LDS-DMA kernel (igemm_glds_impl.h, TERMS 5 / 6).
 #include "igemm_params.h"
 #include <cstdlib>
 #include <type_traits>
@@ -67,6 +72,9 @@ __device__ __forceinline__ void store4(u16* dst, int lo_off, float4 v) {
   }
 }
 
+template <int TERMS>
+__device__ __forceinline__ void store4(u16* dst, int, uint2 v) { *reinterpret_cast<uint2*>(dst) = v; }
+
 template <typename H8>
 __device__ __forceinline__ H8 tr_read8(const u16* p, int row_pitch) {
   typedef __attribute__((address_space(3))) s16x4* lds_p;
@@ -75,8 +83,10 @@ __device__ __forceinline__ H8 tr_read8(const u16* p, int row_pitch) {
   return __builtin_bit_cast(H8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int OP, int BM, int BN, int TERMS>
+template <int OP, int BM, int BN, int TERMS, bool IN16 = false>
 __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
+  using T = std::conditional_t<IN16, u16, float>;          // element type of A / B in HBM
+  using R4 = std::conditional_t<IN16, uint2, float4>;      // four of them in registers
   constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
   constexpr bool SPLIT = TERMS == 3;
   constexpr int IMGS = SPLIT ? 2 : 1;
@@ -110,15 +120,15 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
     kcls = nr * ns * p.Cout;
   }
   const int zo = z / p.batch_inner, zi = z - zo * p.batch_inner;
-  const float* __restrict__ Ag = p.A + zo * p.sAo + zi * p.sAi;
-  const float* __restrict__ Bg = p.B + zo * p.sBo + zi * p.sBi;
+  const T* __restrict__ Ag = reinterpret_cast<const T*>(p.A) + zo * p.sAo + zi * p.sAi;
+  const T* __restrict__ Bg = reinterpret_cast<const T*>(p.B) + zo * p.sBo + zi * p.sBi;
   const long coff = zo * p.sCo + zi * p.sCi;
   const int kbeg = split * p.kps;
   const int kend = OP == ICK_OP_CONV_DGRAD_S2 ? kcls : min(p.K, kbeg + p.kps);
   const int nkt = (kend - kbeg + BK - 1) / BK;
 
   // ---------------------------------------------------------------- per-thread fetch state
-  const float* a_ptr[PA]; bool a_ok[PA]; int a_y[PA], a_x[PA];
+  const T* a_ptr[PA]; bool a_ok[PA]; int a_y[PA], a_x[PA];
   const int a_k4 = (tid & 7) * 4;   // k offset inside the tile (k-contiguous fetch: 8 threads x 16 B = one 128-B row)
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
       a_ptr[i] = Ag + m; a_y[i] = i * A_KR + tid / A_TPK; a_x[i] = 0;
     }
   }
-  const float* b_ptr[PB]; bool b_ok[PB]; int b_y[PB];
+  const T* b_ptr[PB]; bool b_ok[PB]; int b_y[PB];
   int b_r = 0, b_s = 0;
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
     }
   }
 
-  float4 ra[PA], rb[PB];
+  R4 ra[PA], rb[PB];
   unsigned amask = 0, bmask = 0;
 
   auto fetch = [&](int kt) {
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
     u16* Bb = Ab + IMGS * A_SZ;
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-      float4 v = keep_if(ra[i], (amask >> i) & 1u);
+      R4 v = keep_if(ra[i], (amask >> i) & 1u);
       if constexpr (AK) {
         if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) v = ktail(v, kq, kend);
         store4<TERMS>(Ab + (i * 32 + (tid >> 3)) * KCP + a_k4, A_SZ, v);
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
-      float4 v = keep_if(rb[i], (bmask >> i) & 1u);
+      R4 v = keep_if(rb[i], (bmask >> i) & 1u);
       if constexpr (BKc) {
         v = ktail(v, kq, kend);
         store4<TERMS>(Bb + (i * 32 + (tid >> 3)) * KCP + a_k4, B_SZ, v);
@@ -430,11 +440,20 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
           mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
         }
         float4 v = *reinterpret_cast<const float4*>(ct + row * BN + col);
+        using h4 = typename Half16<TERMS>::x4;
         if (Rg) {
-          const float4 q = *reinterpret_cast<const float4*>(Rg + mr * p.ldr + n);
+          float4 q;
+          if (IN16 && p.r16) q = ld4h<h4>(p.residual, coff + mr * p.ldr + n);
+          else q = *reinterpret_cast<const float4*>(Rg + mr * p.ldr + n);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
         if (post) { v.x = act_fn(v.x, act); v.y = act_fn(v.y, act); v.z = act_fn(v.z, act); v.w = act_fn(v.w, act); }
+        if (IN16 && p.c16) {                 // 16-bit C: 8-byte row chunks
+          const long o = coff + mr * p.ldc + n;
+          if (mode == 1) { const float4 q = ld4h<h4>(p.C, o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          st4h<h4>(p.C, o, v);
+          continue;
+        }
         float4* dst = reinterpret_cast<float4*>(Cg + mr * p.ldc + n);
         if (mode == 1) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *dst = v;
@@ -487,7 +506,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
   else epilogue(std::false_type{});
 }
 
-template <int OP, int BM, int BN, int TERMS>
+template <int OP, int BM, int BN, int TERMS, bool IN16>
 int launch(const P& p0, int nz, hipStream_t st) {
   P p = p0;
   p.tiles_n = (p.N + BN - 1) / BN;
@@ -495,15 +514,17 @@ int launch(const P& p0, int nz, hipStream_t st) {
              (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual)));
   if ((p.col_scale || (p.act & ICK_ACT_POST_RESIDUAL)) && !(p.ep_vec && p.splitk == 1))
     return ick::fail(-1, "igemm: col_scale / ICK_ACT_POST_RESIDUAL need 16-byte aligned C rows (N %% 4, ldc %% 4) and no split-K");
+  if ((p.c16 || p.r16) && !(IN16 && p.ep_vec && p.splitk == 1))
+    return ick::fail(-1, "igemm: a 16-bit C / residual needs the native 16-bit kernel, N %% 4, ldc %% 4, ldr %% 4 and no split-K");
   dim3 grid(p.tiles_n * ((p.M + BM - 1) / BM), 1, nz);
-  ICK_LAUNCH((igemm_bf16_kernel<OP, BM, BN, TERMS>), grid, dim3(NT), 0, st, p);
+  ICK_LAUNCH((igemm_bf16_kernel<OP, BM, BN, TERMS, IN16>), grid, dim3(NT), 0, st, p);
   return ick::launch_status("igemm_bf16");
 }
 
 // Tile choice: the same wave-quantisation model as the fp32 family (max work per CU), with a flatter efficiency
 // ladder: at bf16 MFMA rates every tile shape is fed by the fp32 operand stream from L2, not by the matrix pipe.
 // The split (TERMS == 3) 128x128 tile would need 80 KB of LDS per workgroup; it is not built.
-template <int OP, int TERMS>
+template <int OP, int TERMS, bool IN16>
 int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
   constexpr bool BIG = TERMS != 3;
   if (tile == 0 || (!BIG && tile == 1)) {
@@ -519,26 +540,26 @@ int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
     }
   }
   switch (tile) {
-    case 2: return launch<OP, 64, 64, TERMS>(p, nz, st);
-    case 3: return launch<OP, 128, 64, TERMS>(p, nz, st);
-    case 4: return launch<OP, 64, 128, TERMS>(p, nz, st);
+    case 2: return launch<OP, 64, 64, TERMS, IN16>(p, nz, st);
+    case 3: return launch<OP, 128, 64, TERMS, IN16>(p, nz, st);
+    case 4: return launch<OP, 64, 128, TERMS, IN16>(p, nz, st);
     default:
-      if constexpr (BIG) return launch<OP, 128, 128, TERMS>(p, nz, st);
-      else return launch<OP, 128, 64, TERMS>(p, nz, st);
+      if constexpr (BIG) return launch<OP, 128, 128, TERMS, IN16>(p, nz, st);
+      else return launch<OP, 128, 64, TERMS, IN16>(p, nz, st);
   }
 }
 
-template <int TERMS>
+template <int TERMS, bool IN16 = false>
 int run(const IckGemm* d, const P& p, int nz, hipStream_t st) {
   switch (d->op) {
-    case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
-    case ICK_OP_NN: return dispatch_tile<ICK_OP_NN, TERMS>(p, nz, st, d->tile);
-    case ICK_OP_TN: return dispatch_tile<ICK_OP_TN, TERMS>(p, nz, st, d->tile);
-    case ICK_OP_CONV_FWD: return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
-    case ICK_OP_CONV_FWD_C4: return dispatch_tile<ICK_OP_CONV_FWD_C4, TERMS>(p, nz, st, d->tile);
-    case ICK_OP_CONV_DGRAD: return dispatch_tile<ICK_OP_CONV_DGRAD, TERMS>(p, nz, st, d->tile);
-    case ICK_OP_CONV_DGRAD_S2: return dispatch_tile<ICK_OP_CONV_DGRAD_S2, TERMS>(p, 4, st, d->tile);
-    case ICK_OP_CONV_WGRAD: return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS>(p, nz, st, d->tile);
+    case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS, IN16>(p, nz, st, d->tile);
+    case ICK_OP_NN: return dispatch_tile<ICK_OP_NN, TERMS, IN16>(p, nz, st, d->tile);
+    case ICK_OP_TN: return dispatch_tile<ICK_OP_TN, TERMS, IN16>(p, nz, st, d->tile);
+    case ICK_OP_CONV_FWD: return dispatch_tile<ICK_OP_CONV_FWD, TERMS, IN16>(p, nz, st, d->tile);
+    case ICK_OP_CONV_FWD_C4: return dispatch_tile<ICK_OP_CONV_FWD_C4, TERMS, IN16>(p, nz, st, d->tile);
+    case ICK_OP_CONV_DGRAD: return dispatch_tile<ICK_OP_CONV_DGRAD, TERMS, IN16>(p, nz, st, d->tile);
+    case ICK_OP_CONV_DGRAD_S2: return dispatch_tile<ICK_OP_CONV_DGRAD_S2, TERMS, IN16>(p, 4, st, d->tile);
+    case ICK_OP_CONV_WGRAD: return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS, IN16>(p, nz, st, d->tile);
     default: return ick::fail(-1, "ick_gemm_bf16: unknown op %d", d->op);
   }
 }
@@ -548,22 +569,20 @@ int run(const IckGemm* d, const P& p, int nz, hipStream_t st) {
 namespace ickg {
 bool glds_eligible(const IckGemm* d);                                                     // igemm_f32_glds.hip
 int run_glds_bf16(const IckGemm* d, int terms, const P& p, int nz, hipStream_t st);       // igemm_bf16_glds_impl.h
-}
 
-extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
-  ICK_REQUIRE(terms >= 1 && terms <= 3, "ick_gemm_bf16: terms must be 1 (bf16), 2 (fp16) or 3 (split bf16), got %d", terms);
-  P p; int nz = 1;
-  if (int rc = prepare(d, BK, p, nz, "ick_gemm_bf16")) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
+
+// shape rules shared by ick_gemm_bf16 and ick_gemm_h16; *to_f32 = 1: the channel count has no 32-wide k-tile (exact-fp32 kernel)
+int check_bf16_shapes(const IckGemm* d, const P& p, int nz, int* to_f32, const char* who) {
+  *to_f32 = 0;
   switch (d->op) {
     case ICK_OP_NT: case ICK_OP_NN: case ICK_OP_TN:
-      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "ick_gemm_bf16: lda, ldb must be multiples of 4 (rows readable up to roundup4)");
-      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "ick_gemm_bf16: batch strides must be multiples of 4");
+      ICK_REQUIRE(p.lda % 4 == 0 && p.ldb % 4 == 0, "%s: lda, ldb must be multiples of 4 (rows readable up to roundup4)", who);
+      ICK_REQUIRE((p.sAo | p.sAi | p.sBo | p.sBi) % 4 == 0, "%s: batch strides must be multiples of 4", who);
       break;
     case ICK_OP_CONV_FWD:
       ICK_REQUIRE(p.M == p.Nb * p.Ho * p.Wo && p.N == p.Cout && p.K == p.R * p.S * p.Cin && p.ldb == p.K,
                   "CONV_FWD: M/N/K do not match the geometry");
-      if (p.Cin % BK != 0) return ick_gemm_f32(d, stream);   // a k-tile must not straddle two taps: exact-fp32 kernel (BK 16)
+      if (p.Cin % BK != 0) *to_f32 = 1;   // a k-tile must not straddle two taps: exact-fp32 kernel (BK 16)
       break;
     case ICK_OP_CONV_FWD_C4:
       ICK_REQUIRE(p.Cin == 4, "CONV_FWD_C4: Cin must be 4");
@@ -574,14 +593,14 @@ extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
       ICK_REQUIRE(p.Cin % 4 == 0, "CONV_DGRAD: Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Nb * p.H * p.W && p.N == p.Cin && p.K == p.R * p.S * p.Cout,
                   "CONV_DGRAD: M/N/K do not match the geometry");
-      if (p.Cout % BK != 0) return ick_gemm_f32(d, stream);
+      if (p.Cout % BK != 0) *to_f32 = 1;
       break;
     case ICK_OP_CONV_DGRAD_S2:
       ICK_REQUIRE(p.stride == 2 && p.H % 2 == 0 && p.W % 2 == 0, "CONV_DGRAD_S2: stride 2 and even H, W required");
       ICK_REQUIRE(p.Cin % 4 == 0, "CONV_DGRAD_S2: Cin %% 4 required");
       ICK_REQUIRE(p.M == p.Nb * (p.H / 2) * (p.W / 2) && p.N == p.Cin && p.K == p.R * p.S * p.Cout && nz == 1 &&
                   p.splitk == 1, "CONV_DGRAD_S2: M must be the rows of ONE parity class; no batching / split-K");
-      if (p.Cout % BK != 0) return ick_gemm_f32(d, stream);
+      if (p.Cout % BK != 0) *to_f32 = 1;
       break;
     case ICK_OP_CONV_WGRAD:
       ICK_REQUIRE(p.Cout % 4 == 0 && p.Cin % 4 == 0, "CONV_WGRAD: Cout %% 4 and Cin %% 4 required");
@@ -589,8 +608,29 @@ extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
                   "CONV_WGRAD: M/N/K do not match the geometry");
       break;
     default:
-      return ick::fail(-1, "ick_gemm_bf16: unknown op %d", d->op);
+      return ick::fail(-1, "%s: unknown op %d", who, d->op);
   }
+  return 0;
+}
+
+// register-staged kernel on native 16-bit operands (entry: igemm_h16.hip); shapes already checked by the caller
+int run_regs_h16(const IckGemm* d, int fp16, const P& p, int nz, hipStream_t st) {
+  IckGemm dd = *d; dd.tile &= 15;
+  return fp16 ? run<2, true>(&dd, p, nz, st) : run<1, true>(&dd, p, nz, st);
+}
+}  // namespace ickg
+
+extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
+  using namespace ickg;
+  ICK_REQUIRE(terms >= 1 && terms <= 3, "ick_gemm_bf16: terms must be 1 (bf16), 2 (fp16) or 3 (split bf16), got %d", terms);
+  ICK_REQUIRE(d != nullptr, "ick_gemm_bf16: null descriptor");
+  ICK_REQUIRE(d->io16 == 0 || terms != 3, "ick_gemm_bf16: a 16-bit C / residual needs terms 1 (bf16) or 2 (fp16)");
+  P p; int nz = 1;
+  if (int rc = prepare(d, BK, p, nz, "ick_gemm_bf16")) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int to_f32 = 0;
+  if (int rc = check_bf16_shapes(d, p, nz, &to_f32, "ick_gemm_bf16")) return rc;
+  if (to_f32) return ick_gemm_f32(d, stream);
   // the LDS-DMA variant (igemm_bf16_glds_impl.h) is the default where it exists; IckGemm.tile bit 8 or ICK_NO_GLDS_BF16=1
   // selects this file's register-staged kernel (conv wgrad always: both operands x-contiguous + per-lane gather)
   static const bool no_glds = [] { const char* e = getenv("ICK_NO_GLDS_BF16"); return e && e[0] == '1'; }();

@@ -458,6 +458,7 @@ static bool want_glds(const IckGemm* d) {
 
 extern "C" int ick_gemm_f32(const IckGemm* d0, void* stream) {
   ICK_REQUIRE(d0 != nullptr, "ick_gemm_f32: null descriptor");
+  ICK_REQUIRE(d0->io16 == 0, "ick_gemm_f32: C and the residual are fp32 here (io16 belongs to ick_gemm_h16 / ick_gemm_bf16)");
   const bool fused_bn = d0->col_scale || (d0->act & ICK_ACT_POST_RESIDUAL);   // only the LDS-DMA kernel implements these
   const bool glds = want_glds(d0) || (fused_bn && glds_eligible(d0));
   ICK_REQUIRE(glds || (!d0->col_scale && !(d0->act & ICK_ACT_POST_RESIDUAL)),

@@ -46,9 +46,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-template <int TERMS> struct Half16 { using x8 = bf16x8; };
-template <> struct Half16<2> { using x8 = f16x8; };   // fp16: 10 mantissa bits, 5-bit exponent — run under the device GradScaler
-template <> struct Half16<6> { using x8 = f16x8; };
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <int TERMS> struct Half16 { using x8 = bf16x8; using x4 = bf16x4; };
+template <> struct Half16<2> { using x8 = f16x8; using x4 = f16x4; };   // fp16: 10 mantissa bits, 5-bit exponent — run under the device GradScaler
+template <> struct Half16<6> { using x8 = f16x8; using x4 = f16x4; };
 template <int TERMS, typename V>
 __device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
   if constexpr (TERMS == 2 || TERMS == 6) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
   constexpr int A_SZ = BM * BK, B_SZ = BN * BK, BUF = A_SZ + B_SZ;
   constexpr int A_TPK = BM / 4, B_TPK = BN / 4;        // lanes per k-row of an x-contiguous image
   constexpr int A_RPI = 64 / A_TPK, B_RPI = 64 / B_TPK;  // k-rows per DMA instruction (x-contiguous)
+  constexpr bool H16OUT = TERMS != 0 && TERMS != 3;       // variants that can write C / read the residual as 16-bit (P.c16 / P.r16)
 
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF];
 
@@ -510,11 +513,20 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
           mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
         }
         float4 v = *reinterpret_cast<const float4*>(ct + row * BN + col);
+        using h4 = typename Half16<TERMS>::x4;
         if (Rg) {
-          const float4 q = *reinterpret_cast<const float4*>(Rg + mr * p.ldr + n);
+          float4 q;
+          if (H16OUT && p.r16) q = ld4h<h4>(p.residual, coff + mr * p.ldr + n);
+          else q = *reinterpret_cast<const float4*>(Rg + mr * p.ldr + n);
           v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
         }
         if (post) { v.x = act_fn(v.x, act); v.y = act_fn(v.y, act); v.z = act_fn(v.z, act); v.w = act_fn(v.w, act); }
+        if (H16OUT && p.c16) {           // 16-bit C: 8-byte row chunks
+          const long o = coff + mr * p.ldc + n;
+          if (mode == 1) { const float4 q = ld4h<h4>(p.C, o); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+          st4h<h4>(p.C, o, v);
+          continue;
+        }
         float4* dst = reinterpret_cast<float4*>(Cg + mr * p.ldc + n);
         if (mode == 1) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *dst = v;
@@ -585,6 +597,8 @@ int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) 
              (!p.residual || (p.ldr % 4 == 0 && ick::aligned16(p.residual))) && !g_no_vec_epilogue && !p.no_ep_vec;
   if ((p.col_scale || (p.act & ICK_ACT_POST_RESIDUAL)) && !(p.ep_vec && p.splitk == 1))
     return ick::fail(-1, "igemm: col_scale / ICK_ACT_POST_RESIDUAL need 16-byte aligned C rows (N %% 4, ldc %% 4) and no split-K");
+  if ((p.c16 || p.r16) && !((TERMS != 0 && TERMS != 3) && p.ep_vec && p.splitk == 1))
+    return ick::fail(-1, "igemm: a 16-bit C / residual needs a 16-bit MFMA variant of the LDS-DMA kernel, N %% 4, ldc %% 4, ldr %% 4 and no split-K");
   dim3 grid(p.tiles_n * ((p.M - m_begin + BM - 1) / BM), 1, nz);
   ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>), grid, dim3(NW * 64), 0, st, p);
   return ick::launch_status("igemm_glds");
@@ -661,8 +675,11 @@ namespace ickg {
 // argument checks are done by the caller; p/nz come from prepare(d, 32, ...); eligibility = glds_eligible(d)
 int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
   constexpr int TERMS = ICK_GLDS_TERMS;
-  if constexpr (TERMS >= 5)
-    if (d->op != ICK_OP_NT && d->op != ICK_OP_CONV_FWD) return ick::fail(-1, "igemm (native 16-bit): k-contiguous operands only (NT, CONV_FWD), got op %d", d->op);
+  if constexpr (TERMS >= 5) {   // both operands k-contiguous: the only ops whose 16-bit image the fp32 addressing can carry
+    if (d->op == ICK_OP_NT) return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
+    if (d->op == ICK_OP_CONV_FWD) return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
+    return ick::fail(-1, "igemm (native 16-bit, LDS-DMA): NT and CONV_FWD only, got op %d", d->op);
+  } else
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
     case ICK_OP_NN: return dispatch_tile<ICK_OP_NN, TERMS>(p, nz, st, d->tile);

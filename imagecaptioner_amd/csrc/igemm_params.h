@@ -22,6 +22,7 @@ struct P {  // kernel parameters (by value)
   int m_base;        // first row of this launch (M-split dispatch; 0 for a whole-problem launch)
   int chunk_tiles;   // fold the MFMA accumulators into the master sum every chunk_tiles k-tiles (0 = never)
   int ep_vec;   // LDS-staged 16-byte epilogue allowed (set by the launcher from the alignment of C / residual)
+  int c16, r16;   // native 16-bit kernels only (IckGemm.io16): C / the residual hold bf16 or fp16 elements (the operand type)
 };
 
 // which fetch pattern each op uses for its A and B operands
@@ -51,6 +52,27 @@ __device__ __forceinline__ float4 ktail(float4 v, int k, int kend) {
   return v;
 }
 
+// native 16-bit operands (IN16 kernels): four halves = 8 bytes, same guarded branch-free form
+__device__ __forceinline__ uint2 ldg4u(const unsigned short* p, bool ok, const unsigned short* safe) {
+  return *reinterpret_cast<const uint2*>(ok ? p : safe);
+}
+__device__ __forceinline__ uint2 keep_if(uint2 v, bool ok) { return make_uint2(ok ? v.x : 0u, ok ? v.y : 0u); }
+__device__ __forceinline__ uint2 ktail(uint2 v, int, int) { return v; }   // IN16 requires K % 4 == 0: no partial group
+
+// 16-bit C / residual rows of the native 16-bit kernels: four elements = 8 bytes (H4 = bf16x4 or f16x4)
+template <typename H4>
+__device__ __forceinline__ float4 ld4h(const void* base, long idx) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 f = __builtin_convertvector(*reinterpret_cast<const H4*>(reinterpret_cast<const unsigned short*>(base) + idx), f4);
+  return make_float4(f.x, f.y, f.z, f.w);
+}
+template <typename H4>
+__device__ __forceinline__ void st4h(void* base, long idx, float4 v) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const f4 f = {v.x, v.y, v.z, v.w};
+  *reinterpret_cast<H4*>(reinterpret_cast<unsigned short*>(base) + idx) = __builtin_convertvector(f, H4);
+}
+
 __device__ __forceinline__ float act_fn(float v, int act) {
   if (act == ICK_ACT_RELU) return v > 0.f ? v : 0.f;
   if (act == ICK_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
@@ -69,6 +91,7 @@ inline int prepare(const IckGemm* d, int bk, P& p, int& nz, const char* who) {
   p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
   p.stat_sum = d->stat_sum; p.stat_sq = d->stat_sq;
   p.col_scale = d->col_scale;
+  p.c16 = d->io16 & 1; p.r16 = (d->io16 >> 1) & 1;
   p.stat_copies = d->stat_copies > 1 ? d->stat_copies : 1; p.stat_stride = d->stat_stride;
   ICK_REQUIRE(p.stat_copies == 1 || p.stat_stride >= d->N, "%s: stat_stride must be >= N", who);
   p.M = d->M; p.N = d->N; p.K = d->K;

@@ -28,6 +28,28 @@ inline int grid_for(long work_items, int per_block = NT, int cap = 2048) {
   return (int)g;
 }
 
+// Storage type of the trunk's activations: float, or __bf16 / _Float16 in the 16-bit training regime (the reference's
+// autocast keeps them in fp16, train_student_kd.py:271).  ld4 / st4 move four consecutive elements (16 or 8 bytes), index in
+// units of four; arithmetic is always fp32 (statistics fp64).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+template <typename T> struct Vec4 { typedef T type __attribute__((ext_vector_type(4))); };
+template <typename T>
+__device__ __forceinline__ float4 ld4(const T* p, long i) {
+  if constexpr (sizeof(T) == 4) return reinterpret_cast<const float4*>(p)[i];
+  else {
+    const f32x4_t f = __builtin_convertvector(reinterpret_cast<const typename Vec4<T>::type*>(p)[i], f32x4_t);
+    return make_float4(f.x, f.y, f.z, f.w);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* p, long i, float4 v) {
+  if constexpr (sizeof(T) == 4) reinterpret_cast<float4*>(p)[i] = v;
+  else {
+    const f32x4_t f = {v.x, v.y, v.z, v.w};
+    reinterpret_cast<typename Vec4<T>::type*>(p)[i] = __builtin_convertvector(f, typename Vec4<T>::type);
+  }
+}
+
 // ------------------------------------------------------------------ layout transforms
 // images (B,3,H,W) fp32 NCHW -> (B,H,W,4) NHWC with a zero 4th channel (16-B pixels for the stem conv)
 __global__ void nchw3_to_nhwc4_kernel(const float* __restrict__ x, float* __restrict__ y, long npix, long hw) {
@@ -63,14 +85,15 @@ __global__ void patchify16_kernel(const float* __restrict__ x, float* __restrict
 // conv weight [Cout][R][S][Cin] -> the layout its stride-1 data gradient reads as a FORWARD convolution over dY:
 // wt[ci][R-1-r][S-1-s][co] = w[co][r][s][ci]  (taps flipped, channels swapped).  One 32x32 (co x ci) tile per block
 // and tap, transposed through LDS so that both the read (along ci) and the write (along co) are 128-byte rows.
-__global__ void conv_weight_dgrad_layout_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cout, int taps, int Cin) {
-  __shared__ float tile[32][33];
+template <typename T>
+__global__ void conv_weight_dgrad_layout_kernel(const T* __restrict__ w, T* __restrict__ wt, int Cout, int taps, int Cin) {
+  __shared__ T tile[32][33];
   const int tap = blockIdx.z, ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: 8 rows per pass
 #pragma unroll
   for (int r = ty; r < 32; r += 8) {
     const int co = co0 + r, ci = ci0 + tx;
-    tile[r][tx] = (co < Cout && ci < Cin) ? w[((long)co * taps + tap) * Cin + ci] : 0.f;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((long)co * taps + tap) * Cin + ci] : T(0);
   }
   __syncthreads();
   const int tflip = taps - 1 - tap;    // (R-1-r)*S + (S-1-s) = R*S-1 - (r*S+s)
@@ -165,10 +188,11 @@ __global__ void scale_shift_act_kernel(const float* __restrict__ x, const float*
   }
 }
 
-__global__ void bn_train_apply_kernel(const float* __restrict__ x, const double* __restrict__ sum,
+template <typename T>
+__global__ void bn_train_apply_kernel(const T* __restrict__ x, const double* __restrict__ sum,
                                       const double* __restrict__ sq, int copies, long stride, float count, const float* __restrict__ gamma,
                                       const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
-                                      float momentum, float eps, const float* __restrict__ res, float* __restrict__ y,
+                                      float momentum, float eps, const T* __restrict__ res, T* __restrict__ y,
                                       float* __restrict__ smean, float* __restrict__ sinv, long total4, int C4, int relu) {
   const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
   const int c4 = (int)(i0 % C4);
@@ -224,14 +248,14 @@ __global__ void bn_train_apply_kernel(const float* __restrict__ x, const double*
     }
   }
   for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 v = ld4(x, i);
     float4 o = make_float4(fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3]));
     if (res) {
-      const float4 r = reinterpret_cast<const float4*>(res)[i];
+      const float4 r = ld4(res, i);
       o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    reinterpret_cast<float4*>(y)[i] = o;
+    st4(y, i, o);
   }
 }
 
@@ -242,8 +266,9 @@ __global__ void bn_train_apply_kernel(const float* __restrict__ x, const double*
 // thread, fp64 LDS combine, fp64 atomics; invstd is applied once to the finished dot product.  (Both sums are
 // differences of large terms behind a mean-subtracting layer; the kernel is HBM-bound, the fp64 VALU work is free.)
 struct d4 { double x, y, z, w; };
-__global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                     const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                     const T* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ inv, double* __restrict__ sum_g,
                                      double* __restrict__ sum_gx, int copies, long stride, long M, int C, float hi) {
   const int C4 = C >> 2;
@@ -267,9 +292,9 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const long o = (m + u * step) * C4 + c4;
-          g[u] = reinterpret_cast<const float4*>(dy)[o];
-          xv[u] = reinterpret_cast<const float4*>(x)[o];
-          if (y) yy[u] = reinterpret_cast<const float4*>(y)[o];
+          g[u] = ld4(dy, o);
+          xv[u] = ld4(x, o);
+          if (y) yy[u] = ld4(y, o);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -284,13 +309,13 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ dy, const float* 
       }
       for (; m < M; m += step) {
         const long o = m * C4 + c4;
-        float4 g = reinterpret_cast<const float4*>(dy)[o];
+        float4 g = ld4(dy, o);
         if (y) {
-          const float4 yy = reinterpret_cast<const float4*>(y)[o];
+          const float4 yy = ld4(y, o);
           g.x = (yy.x > 0.f && yy.x < hi) ? g.x : 0.f; g.y = (yy.y > 0.f && yy.y < hi) ? g.y : 0.f;
           g.z = (yy.z > 0.f && yy.z < hi) ? g.z : 0.f; g.w = (yy.w > 0.f && yy.w < hi) ? g.w : 0.f;
         }
-        const float4 xv = reinterpret_cast<const float4*>(x)[o];
+        const float4 xv = ld4(x, o);
         dg.x += g.x; dg.y += g.y; dg.z += g.z; dg.w += g.w;
         dx.x = fma((double)g.x, (double)xv.x - mu.x, dx.x); dx.y = fma((double)g.y, (double)xv.y - mu.y, dx.y);
         dx.z = fma((double)g.z, (double)xv.z - mu.z, dx.z); dx.w = fma((double)g.w, (double)xv.w - mu.w, dx.w);
@@ -330,10 +355,11 @@ __global__ void bn_bwd_fold_kernel(const double* __restrict__ sum_g, const doubl
 
 // BN backward pass 2b: dx = gamma*inv*(g - mean_g - xhat*mean_gx); optionally also writes g (the gradient that
 // flows on into the residual branch).  In eval mode (use_batch_stats == 0): dx = gamma*inv*g.
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                    const float* __restrict__ x, const float* __restrict__ mean,
+template <typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                    const T* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ inv, const float* __restrict__ gamma,
-                                    const float* __restrict__ coef, float* __restrict__ dx, float* __restrict__ gout,
+                                    const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ gout,
                                     long total4, int C4, int use_batch_stats, int hoist, float hi) {
   // hoist: the grid stride is a multiple of C4 (launcher), so a thread's 4 channels never change: per-channel terms once.
   // Otherwise (C/4 neither divides nor is a multiple of 256: MobileNetV2's 96, 144, 576 ...) they are re-read per element.
@@ -358,16 +384,16 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
         mx = reinterpret_cast<const float4*>(coef)[C4 + c];
       }
     }
-    float4 g = reinterpret_cast<const float4*>(dy)[i];
+    float4 g = ld4(dy, i);
     if (y) {
-      const float4 yy = reinterpret_cast<const float4*>(y)[i];
+      const float4 yy = ld4(y, i);
       g.x = (yy.x > 0.f && yy.x < hi) ? g.x : 0.f; g.y = (yy.y > 0.f && yy.y < hi) ? g.y : 0.f;
       g.z = (yy.z > 0.f && yy.z < hi) ? g.z : 0.f; g.w = (yy.w > 0.f && yy.w < hi) ? g.w : 0.f;
     }
-    if (gout) reinterpret_cast<float4*>(gout)[i] = g;
+    if (gout) st4(gout, i, g);
     float4 o;
     if (use_batch_stats) {
-      const float4 xv = reinterpret_cast<const float4*>(x)[i];
+      const float4 xv = ld4(x, i);
       o.x = ga.x * iv.x * (g.x - mg.x - (xv.x - mu.x) * iv.x * mx.x);
       o.y = ga.y * iv.y * (g.y - mg.y - (xv.y - mu.y) * iv.y * mx.y);
       o.z = ga.z * iv.z * (g.z - mg.z - (xv.z - mu.z) * iv.z * mx.z);
@@ -375,12 +401,13 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     } else {
       o = make_float4(ga.x * iv.x * g.x, ga.y * iv.y * g.y, ga.z * iv.z * g.z, ga.w * iv.w * g.w);
     }
-    reinterpret_cast<float4*>(dx)[i] = o;
+    st4(dx, i, o);
   }
 }
 
 // ------------------------------------------------------------------ max-pool 3x3 / stride 2 / pad 1, NHWC
-__global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C4,
+template <typename T>
+__global__ void maxpool3x3s2_kernel(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C4,
                                     int Ho, int Wo) {
   const long total = (long)B * Ho * Wo * C4;
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -398,11 +425,11 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ x, float* __restri
       for (int dx = 0; dx < 3; ++dx) {
         const int ix = ox * 2 - 1 + dx;
         if ((unsigned)ix >= (unsigned)W) continue;
-        const float4 v = reinterpret_cast<const float4*>(x)[((b * H + iy) * W + ix) * C4 + c];
+        const float4 v = ld4(x, ((b * H + iy) * W + ix) * C4 + c);
         m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
       }
     }
-    reinterpret_cast<float4*>(y)[i] = m;
+    st4(y, i, m);
   }
 }
 
@@ -694,7 +721,130 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 
 #define ST static_cast<hipStream_t>(stream)
 
+// ---- launchers of the storage-type templated kernels (fp32 and 16-bit entry points below)
+template <typename T>
+int bn_bwd_reduce_impl(const T* dy, const T* y, const T* x, const float* mean, const float* invstd,
+                      double* sum_g, double* sum_gx, int copies, int64_t stride, long M, int C, int act, void* stream) {
+  ICK_REQUIRE(copies >= 1 && (copies == 1 || stride >= C), "ick_bn_bwd_reduce: copies >= 1, stride >= C");
+  ICK_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && C % 4 == 0 && M > 0, "ick_bn_bwd_reduce: bad arguments");
+  const int C4 = C / 4;
+  const int lanes = C4 < NT ? C4 : NT;
+  const int rows = NT / lanes;
+  const int gx = (C4 + lanes - 1) / lanes;
+  // Grid: ~200 workgroups in all.  Every workgroup ends with 2 x 4 x lanes fp64 atomics onto the same 2 x C addresses and
+  // those — not the 12 B/element stream — set the time: measured (tools/bench_bn.py, M = 12544, C = 1024) 123 us with 3136
+  // row-blocks, 55 us with 784, 27 us (5.7 TB/s) with 196; fewer than ~100 starves the memory system again.
+  static const int target = [] { const char* e = getenv("ICK_BN_BWD_BLOCKS"); return e ? atoi(e) : 200; }();   // A/B runs
+  long gy = target / gx;
+  const long gmax = (M + rows * 4 - 1) / (rows * 4);          // at least one 4-row trip per thread
+  if (gy > gmax) gy = gmax;
+  if (gy < 1) gy = 1;
+  ICK_LAUNCH(bn_bwd_reduce_kernel<T>, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, copies, (long)stride, M, C,
+             act == 2 ? 6.f : INFINITY);
+  return ick::launch_status("bn_bwd_reduce");
+}
+
+template <typename T>
+int bn_bwd_apply_impl(const T* dy, const T* y, const T* x, const float* mean, const float* invstd,
+                     const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws,
+                     T* dx, T* g_out, long M, int C, int use_batch_stats, float* dgamma, float* dbeta, int act, void* stream) {
+  if (copies < 1) copies = 1;
+  ICK_REQUIRE(dy && x && mean && invstd && gamma && dx && C % 4 == 0 && M > 0, "ick_bn_bwd_apply: bad arguments");
+  ICK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "ick_bn_bwd_apply: dgamma and dbeta go together");
+  ICK_REQUIRE(!use_batch_stats || (sum_g && sum_gx && coef_ws), "ick_bn_bwd_apply: batch statistics need the two sums and the 2*C workspace");
+  const int C4 = C / 4;
+  const int hoist = (C4 <= NT ? NT % C4 == 0 : C4 % NT == 0) ? 1 : 0;
+  if (use_batch_stats)
+    ICK_LAUNCH(bn_bwd_fold_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum_g, sum_gx, copies, (long)stride, 1.0 / (double)M,
+               coef_ws, dgamma, dbeta, C);
+  const long total4 = M * C4;
+  int grid = grid_for(total4);
+  const int q = (hoist && C4 > NT) ? C4 / NT : 1;          // grid * NT must be a multiple of C4: a thread keeps its channels
+  grid = (grid + q - 1) / q * q;
+  ICK_LAUNCH(bn_bwd_apply_kernel<T>, dim3(grid), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, coef_ws, dx, g_out, total4, C4,
+             use_batch_stats, hoist, act == 2 ? 6.f : INFINITY);
+  return ick::launch_status("bn_bwd_apply");
+}
+
+template <typename T>
+int bn_train_apply_impl(const T* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, const T* residual,
+                       T* y, float* save_mean, float* save_invstd, long M, int C, int relu, void* stream) {
+  ICK_REQUIRE(x && sum && sq && gamma && beta && y && save_mean && save_invstd && M > 0 && C % 4 == 0 && (C / 4) <= 1024 &&
+              ((C / 4) & (C / 4 - 1)) == 0, "ick_bn_train_apply: C/4 must be a power of two <= 1024");
+  const int C4 = C / 4;
+  const long total4 = M * C4;
+  int grid = grid_for(total4);
+  const int q = C4 > NT ? C4 / NT : 1;          // grid * NT must be a multiple of C4
+  grid = (grid + q - 1) / q * q;
+  ICK_REQUIRE(stat_copies <= 1 || C <= 1024, "ick_bn_train_apply: accumulator copies are supported up to C = 1024 (C = %d)", C);
+  ICK_LAUNCH(bn_train_apply_kernel<T>, dim3(grid), dim3(NT), 0, ST, x, sum, sq, stat_copies > 1 ? stat_copies : 1, (long)stat_stride, (float)M, gamma, beta, running_mean,
+             running_var, momentum, eps, residual, y, save_mean, save_invstd, total4, C4, relu);
+  return ick::launch_status("bn_train_apply");
+}
+
+template <typename T>
+int maxpool3x3s2_impl(const T* x, T* y, int B, int H, int W, int C, void* stream) {
+  ICK_REQUIRE(x && y && C % 4 == 0, "ick_maxpool3x3s2: bad arguments");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  ICK_LAUNCH(maxpool3x3s2_kernel<T>, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(NT), 0, ST, x, y, B, H, W, C / 4,
+                     Ho, Wo);
+  return ick::launch_status("maxpool3x3s2");
+}
+
+template <typename T>
+int conv_weight_dgrad_layout_impl(const T* w, T* wt, int Cout, int R, int S, int Cin, void* stream) {
+  ICK_REQUIRE(w && wt && Cout > 0 && R > 0 && S > 0 && Cin > 0 && R * S <= 65535, "ick_conv_weight_dgrad_layout: bad arguments");
+  ICK_LAUNCH(conv_weight_dgrad_layout_kernel<T>, dim3((Cin + 31) / 32, (Cout + 31) / 32, R * S), dim3(NT), 0, ST, w, wt, Cout,
+             R * S, Cin);
+  return ick::launch_status("conv_weight_dgrad_layout");
+}
+
 extern "C" {
+// ---- fp32 and 16-bit entry points of the templated kernels above
+int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                      double* sum_g, double* sum_gx, int copies, int64_t stride, long M, int C, int act, void* stream) {
+  return bn_bwd_reduce_impl<float>(dy, y, x, mean, invstd, sum_g, sum_gx, copies, stride, M, C, act, stream);
+}
+int ick_bn_bwd_reduce16(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                        double* sum_g, double* sum_gx, int copies, int64_t stride, long M, int C, int act, int fp16, void* stream) {
+  if (fp16) return bn_bwd_reduce_impl((const _Float16*)dy, (const _Float16*)y, (const _Float16*)x, mean, invstd, sum_g, sum_gx, copies, stride, M, C, act, stream);
+  return bn_bwd_reduce_impl((const __bf16*)dy, (const __bf16*)y, (const __bf16*)x, mean, invstd, sum_g, sum_gx, copies, stride, M, C, act, stream);
+}
+int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
+                     const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws,
+                     float* dx, float* g_out, long M, int C, int use_batch_stats, float* dgamma, float* dbeta, int act, void* stream) {
+  return bn_bwd_apply_impl<float>(dy, y, x, mean, invstd, gamma, sum_g, sum_gx, copies, stride, coef_ws, dx, g_out, M, C, use_batch_stats, dgamma, dbeta, act, stream);
+}
+int ick_bn_bwd_apply16(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                       const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws,
+                       void* dx, void* g_out, long M, int C, int use_batch_stats, float* dgamma, float* dbeta, int act, int fp16, void* stream) {
+  if (fp16) return bn_bwd_apply_impl((const _Float16*)dy, (const _Float16*)y, (const _Float16*)x, mean, invstd, gamma, sum_g, sum_gx, copies, stride, coef_ws, (_Float16*)dx, (_Float16*)g_out, M, C, use_batch_stats, dgamma, dbeta, act, stream);
+  return bn_bwd_apply_impl((const __bf16*)dy, (const __bf16*)y, (const __bf16*)x, mean, invstd, gamma, sum_g, sum_gx, copies, stride, coef_ws, (__bf16*)dx, (__bf16*)g_out, M, C, use_batch_stats, dgamma, dbeta, act, stream);
+}
+int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
+                       float* running_mean, float* running_var, float momentum, float eps, const float* residual,
+                       float* y, float* save_mean, float* save_invstd, long M, int C, int relu, void* stream) {
+  return bn_train_apply_impl<float>(x, sum, sq, stat_copies, stat_stride, gamma, beta, running_mean, running_var, momentum, eps, residual, y, save_mean, save_invstd, M, C, relu, stream);
+}
+int ick_bn_train_apply16(const void* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, const void* residual,
+                         void* y, float* save_mean, float* save_invstd, long M, int C, int relu, int fp16, void* stream) {
+  if (fp16) return bn_train_apply_impl((const _Float16*)x, sum, sq, stat_copies, stat_stride, gamma, beta, running_mean, running_var, momentum, eps, (const _Float16*)residual, (_Float16*)y, save_mean, save_invstd, M, C, relu, stream);
+  return bn_train_apply_impl((const __bf16*)x, sum, sq, stat_copies, stat_stride, gamma, beta, running_mean, running_var, momentum, eps, (const __bf16*)residual, (__bf16*)y, save_mean, save_invstd, M, C, relu, stream);
+}
+int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) { return maxpool3x3s2_impl<float>(x, y, B, H, W, C, stream); }
+int ick_maxpool3x3s2_16(const void* x, void* y, int B, int H, int W, int C, int fp16, void* stream) {
+  if (fp16) return maxpool3x3s2_impl((const _Float16*)x, (_Float16*)y, B, H, W, C, stream);
+  return maxpool3x3s2_impl((const __bf16*)x, (__bf16*)y, B, H, W, C, stream);
+}
+int ick_conv_weight_dgrad_layout(const float* w, float* wt, int Cout, int R, int S, int Cin, void* stream) {
+  return conv_weight_dgrad_layout_impl<float>(w, wt, Cout, R, S, Cin, stream);
+}
+int ick_conv_weight_dgrad_layout16(const void* w, void* wt, int Cout, int R, int S, int Cin, void* stream) {   /* pure data movement: bf16 and fp16 alike */
+  return conv_weight_dgrad_layout_impl((const unsigned short*)w, (unsigned short*)wt, Cout, R, S, Cin, stream);
+}
+
 
 int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stream) {
   ICK_REQUIRE(x && y && B > 0 && H > 0 && W > 0, "ick_nchw3_to_nhwc4: bad arguments");
@@ -716,12 +866,6 @@ int ick_patchify16(const float* x, float* y, int B, int HW, void* stream) {
   return ick::launch_status("patchify16");
 }
 
-int ick_conv_weight_dgrad_layout(const float* w, float* wt, int Cout, int R, int S, int Cin, void* stream) {
-  ICK_REQUIRE(w && wt && Cout > 0 && R > 0 && S > 0 && Cin > 0 && R * S <= 65535, "ick_conv_weight_dgrad_layout: bad arguments");
-  ICK_LAUNCH(conv_weight_dgrad_layout_kernel, dim3((Cin + 31) / 32, (Cout + 31) / 32, R * S), dim3(NT), 0, ST, w, wt, Cout,
-             R * S, Cin);
-  return ick::launch_status("conv_weight_dgrad_layout");
-}
 
 int ick_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int Ntok, int D, void* stream) {
   ICK_REQUIRE(patch && cls && pos && x && D % 4 == 0, "ick_vit_assemble: bad arguments");
@@ -757,74 +901,12 @@ int ick_scale_shift_act(const float* x, const float* scale, const float* shift, 
   return ick::launch_status("scale_shift_act");
 }
 
-int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                      double* sum_g, double* sum_gx, int copies, int64_t stride, long M, int C, int act, void* stream) {
-  ICK_REQUIRE(copies >= 1 && (copies == 1 || stride >= C), "ick_bn_bwd_reduce: copies >= 1, stride >= C");
-  ICK_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && C % 4 == 0 && M > 0, "ick_bn_bwd_reduce: bad arguments");
-  const int C4 = C / 4;
-  const int lanes = C4 < NT ? C4 : NT;
-  const int rows = NT / lanes;
-  const int gx = (C4 + lanes - 1) / lanes;
-  // Grid: ~200 workgroups in all.  Every workgroup ends with 2 x 4 x lanes fp64 atomics onto the same 2 x C addresses and
-  // those — not the 12 B/element stream — set the time: measured (tools/bench_bn.py, M = 12544, C = 1024) 123 us with 3136
-  // row-blocks, 55 us with 784, 27 us (5.7 TB/s) with 196; fewer than ~100 starves the memory system again.
-  static const int target = [] { const char* e = getenv("ICK_BN_BWD_BLOCKS"); return e ? atoi(e) : 200; }();   // A/B runs
-  long gy = target / gx;
-  const long gmax = (M + rows * 4 - 1) / (rows * 4);          // at least one 4-row trip per thread
-  if (gy > gmax) gy = gmax;
-  if (gy < 1) gy = 1;
-  ICK_LAUNCH(bn_bwd_reduce_kernel, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, copies, (long)stride, M, C,
-             act == 2 ? 6.f : INFINITY);
-  return ick::launch_status("bn_bwd_reduce");
-}
 
-int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
-                     const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws,
-                     float* dx, float* g_out, long M, int C, int use_batch_stats, float* dgamma, float* dbeta, int act, void* stream) {
-  if (copies < 1) copies = 1;
-  ICK_REQUIRE(dy && x && mean && invstd && gamma && dx && C % 4 == 0 && M > 0, "ick_bn_bwd_apply: bad arguments");
-  ICK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "ick_bn_bwd_apply: dgamma and dbeta go together");
-  ICK_REQUIRE(!use_batch_stats || (sum_g && sum_gx && coef_ws), "ick_bn_bwd_apply: batch statistics need the two sums and the 2*C workspace");
-  const int C4 = C / 4;
-  const int hoist = (C4 <= NT ? NT % C4 == 0 : C4 % NT == 0) ? 1 : 0;
-  if (use_batch_stats)
-    ICK_LAUNCH(bn_bwd_fold_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum_g, sum_gx, copies, (long)stride, 1.0 / (double)M,
-               coef_ws, dgamma, dbeta, C);
-  const long total4 = M * C4;
-  int grid = grid_for(total4);
-  const int q = (hoist && C4 > NT) ? C4 / NT : 1;          // grid * NT must be a multiple of C4: a thread keeps its channels
-  grid = (grid + q - 1) / q * q;
-  ICK_LAUNCH(bn_bwd_apply_kernel, dim3(grid), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, coef_ws, dx, g_out, total4, C4,
-             use_batch_stats, hoist, act == 2 ? 6.f : INFINITY);
-  return ick::launch_status("bn_bwd_apply");
-}
 
 // train-mode BatchNorm forward in ONE pass over the raw conv output: every thread derives scale/shift of its own
 // 4 channels from the fp64 batch sums the conv epilogue produced (the grid stride is a multiple of C/4, so a
 // thread's channels never change), block 0 also stores mean / invstd for backward and updates the running stats.
-int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
-                       float* running_mean, float* running_var, float momentum, float eps, const float* residual,
-                       float* y, float* save_mean, float* save_invstd, long M, int C, int relu, void* stream) {
-  ICK_REQUIRE(x && sum && sq && gamma && beta && y && save_mean && save_invstd && M > 0 && C % 4 == 0 && (C / 4) <= 1024 &&
-              ((C / 4) & (C / 4 - 1)) == 0, "ick_bn_train_apply: C/4 must be a power of two <= 1024");
-  const int C4 = C / 4;
-  const long total4 = M * C4;
-  int grid = grid_for(total4);
-  const int q = C4 > NT ? C4 / NT : 1;          // grid * NT must be a multiple of C4
-  grid = (grid + q - 1) / q * q;
-  ICK_REQUIRE(stat_copies <= 1 || C <= 1024, "ick_bn_train_apply: accumulator copies are supported up to C = 1024 (C = %d)", C);
-  ICK_LAUNCH(bn_train_apply_kernel, dim3(grid), dim3(NT), 0, ST, x, sum, sq, stat_copies > 1 ? stat_copies : 1, (long)stat_stride, (float)M, gamma, beta, running_mean,
-             running_var, momentum, eps, residual, y, save_mean, save_invstd, total4, C4, relu);
-  return ick::launch_status("bn_train_apply");
-}
 
-int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
-  ICK_REQUIRE(x && y && C % 4 == 0, "ick_maxpool3x3s2: bad arguments");
-  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  ICK_LAUNCH(maxpool3x3s2_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(NT), 0, ST, x, y, B, H, W, C / 4,
-                     Ho, Wo);
-  return ick::launch_status("maxpool3x3s2");
-}
 
 int ick_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
   ICK_REQUIRE(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "ick_maxpool3x3s2_bwd: bad arguments");

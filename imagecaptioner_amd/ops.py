@@ -66,6 +66,21 @@ def _load_tuned(name: str = "tuned_tiles.json"):
 
 _TUNED = _load_tuned()
 _TUNED_BF16 = _load_tuned("tuned_tiles_bf16.json")     # same keys, for the bf16 / bf16x3 kernel family
+_TUNED_H16 = _load_tuned("tuned_tiles_h16.json")       # same keys, for the native 16-bit operand kernels (ick_gemm_h16)
+_H16 = (torch.bfloat16, torch.float16)
+
+
+def _h16(t: torch.Tensor) -> Optional[torch.dtype]:
+    """The 16-bit storage type of an operand, None for fp32."""
+    return t.dtype if t.dtype in _H16 else None
+
+
+def _io16(c: torch.Tensor, residual: Optional[torch.Tensor], h16) -> int:
+    bits = (1 if c.dtype in _H16 else 0) | (2 if (residual is not None and residual.dtype in _H16) else 0)
+    if bits:
+        assert h16 is not None and c.dtype in (h16, _F32) and (residual is None or residual.dtype in (h16, _F32)), \
+            "16-bit C / residual must have the operands' 16-bit type"
+    return bits
 
 # Arithmetic of every dense contraction (Linear / attention products / convolutions): "f32" = exact fp32 MFMA (the
 # parity regime), "bf16" = bf16 MFMA with fp32 accumulation (the reference's autocast regime, train_student_kd.py:263),
@@ -106,7 +121,9 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
              strides: Tuple[int, int, int, int, int, int] = (0, 0, 0, 0, 0, 0), splitk: int = 1,
              accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
              conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0,
-             col_scale: Optional[int] = None, kchunk: int = 0) -> None:
+             col_scale: Optional[int] = None, kchunk: int = 0, h16: Optional[torch.dtype] = None, io16: int = 0) -> None:
+    """h16 = torch.bfloat16 / torch.float16: A and B hold that type in HBM (ick_gemm_h16); io16 bit 0 / 1: so do C / the
+    residual."""
     d = IckGemm()
     d.A, d.B, d.C = A, B, C
     d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
@@ -121,7 +138,13 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
     d.splitk, d.accumulate, d.alpha = splitk, int(accumulate), alpha
     if conv is not None:
         d.Nb, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.R, d.S, d.stride, d.pad = conv
+    if h16 is not None:
+        d.io16 = io16
+        d.tile = tile or _FORCE_TILE[0] or _TUNED_H16.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
+        check(_lib.lib().ick_gemm_h16(ctypes.byref(d), int(h16 == torch.float16), _st()), "ick_gemm_h16")
+        return
     terms = _PRECISIONS[_PREC[0]]
+    d.io16 = io16        # (fp32 operands: only the bf16 / fp16 LDS-DMA variants can write a 16-bit C; the others refuse)
     if terms:
         d.tile = tile or _FORCE_TILE[0] or _TUNED_BF16.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
         check(_lib.lib().ick_gemm_bf16(ctypes.byref(d), terms, _st()), "ick_gemm_bf16")
@@ -130,35 +153,24 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
     check(_lib.lib().ick_gemm_f32(ctypes.byref(d), _st()), "ick_gemm_f32")
 
 
-def cast16(x: torch.Tensor, fp16: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def cast16(x: torch.Tensor, dtype=torch.bfloat16, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fp32 -> bf16 / fp16 copy (round to nearest even) for the native 16-bit GEMM operands."""
     _chk(x, "x")
-    assert x.is_contiguous() and x.numel() % 4 == 0
-    y = out if out is not None else torch.empty(x.shape, dtype=torch.float16 if fp16 else torch.bfloat16, device=x.device)
-    check(_lib.lib().ick_cast_f32_to_16(x.data_ptr(), y.data_ptr(), x.numel(), int(fp16), _st()), "ick_cast_f32_to_16")
+    if dtype is True or dtype is False:        # (legacy flag: fp16 yes / no)
+        dtype = torch.float16 if dtype else torch.bfloat16
+    assert x.is_contiguous() and x.numel() % 4 == 0 and dtype in _H16
+    y = out if out is not None else torch.empty(x.shape, dtype=dtype, device=x.device)
+    assert y.dtype == dtype and y.numel() == x.numel()
+    check(_lib.lib().ick_cast_f32_to_16(x.data_ptr(), y.data_ptr(), x.numel(), int(dtype == torch.float16), _st()), "ick_cast_f32_to_16")
     return y
 
 
-def gemm_h16_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, ldb: int, ldc: int, *, fp16: bool = False,
-                 bias: Optional[int] = None, residual: Optional[int] = None, ldr: int = 0, act: int = ACT_NONE,
-                 alpha: float = 1.0, accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
-                 conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0,
-                 col_scale: Optional[int] = None) -> None:
-    """C (fp32) = epilogue(A @ B^T) with A, B stored as bf16 / fp16 (ick_gemm_h16: OP_NT and OP_CONV_FWD)."""
-    d = IckGemm()
-    d.A, d.B, d.C = A, B, C
-    d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
-    d.stat_copies, d.stat_stride = stat_copies, stat_stride
-    d.col_scale = col_scale
-    d.op, d.act = op, act
-    d.M, d.N, d.K = M, N, K
-    d.lda, d.ldb, d.ldc, d.ldr = lda, ldb, ldc, ldr
-    d.batch_outer, d.batch_inner = 1, 1
-    d.splitk, d.accumulate, d.alpha = 1, int(accumulate), alpha
-    if conv is not None:
-        d.Nb, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.R, d.S, d.stride, d.pad = conv
-    d.tile = tile or _FORCE_TILE[0]
-    check(_lib.lib().ick_gemm_h16(ctypes.byref(d), int(fp16), _st()), "ick_gemm_h16")
+def cast32(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """bf16 / fp16 -> fp32 copy."""
+    assert x.is_cuda and x.is_contiguous() and x.numel() % 4 == 0 and x.dtype in _H16
+    y = out if out is not None else torch.empty(x.shape, dtype=_F32, device=x.device)
+    check(_lib.lib().ick_cast_16_to_f32(x.data_ptr(), y.data_ptr(), x.numel(), int(x.dtype == torch.float16), _st()), "ick_cast_16_to_f32")
+    return y
 
 
 # ----------------------------------------------------------------------------- Linear
@@ -335,17 +347,29 @@ def conv_out_hw(H: int, W: int, R: int, S: int, stride: int, pad: int) -> Tuple[
 
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
              scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-             relu: bool = False) -> torch.Tensor:
+             relu: bool = False, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """x (Nb,H,W,Cin) physical NHWC contiguous; w physical (Cout,R,S,Cin); returns raw y (Nb,Ho,Wo,Cout) and
     optionally accumulates per-channel sum / sum of squares (BatchNorm batch statistics) into `stats`:
-    (sum, sq) fp64 [Cout] each, or fp64 [Cout] x R copies each as rows of a (R, Cout) tensor (see stat_copies())."""
+    (sum, sq) fp64 [Cout] each, or fp64 [Cout] x R copies each as rows of a (R, Cout) tensor (see stat_copies()).
+    bf16 / fp16 x and w: native 16-bit operands (ick_gemm_h16), y in out_dtype (default: the operands' type)."""
     Nb, H, W, Cin = x.shape
     Cout, R, S, Cin2 = w.shape
-    assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous()
+    assert Cin == Cin2 and x.is_contiguous() and w.is_contiguous() and x.dtype == w.dtype
     Ho, Wo = conv_out_hw(H, W, R, S, stride, pad)
-    y = empty(Nb, Ho, Wo, Cout, device=x.device)
+    h16 = _h16(x)
+    y = torch.empty(Nb, Ho, Wo, Cout, dtype=out_dtype or x.dtype, device=x.device)
     op = OP_CONV_FWD_C4 if Cin == 4 else OP_CONV_FWD
     K = R * S * Cin
+    if h16 is not None or y.dtype != _F32:
+        # (fp32 operands + 16-bit y: the 4-channel stem under ops.precision("bf16" / "fp16") — ick_gemm_bf16 with io16)
+        assert scale is None, "the eval-mode fused form runs on fp32 storage"
+        gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout,
+                 residual=_ptr(residual), ldr=Cout, act=ACT_RELU if relu else ACT_NONE,
+                 stat_sum=_ptr(stats[0]) if stats is not None else None, stat_sq=_ptr(stats[1]) if stats is not None else None,
+                 stat_copies=stats[0].shape[0] if (stats is not None and stats[0].dim() == 2) else 1, stat_stride=Cout,
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), h16=h16,
+                 io16=_io16(y, residual, h16 or y.dtype))
+        return y
     if scale is not None:       # eval-mode conv + BatchNorm (+ residual) (+ ReLU) in ONE kernel: y = relu(scale*conv + shift + res)
         gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout, bias=shift.data_ptr(),
                  col_scale=scale.data_ptr(), residual=_ptr(residual), ldr=Cout,
@@ -369,43 +393,57 @@ def stat_copies(rows: int) -> int:
 
 def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride: int, pad: int,
                residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-               accumulate: bool = False) -> torch.Tensor:
-    """dx (Nb,H,W,Cin) = conv-transpose of dy (Nb,Ho,Wo,Cout) with w (Cout,R,S,Cin) [+ residual]."""
+               accumulate: bool = False, wt_cached: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx (Nb,H,W,Cin) = conv-transpose of dy (Nb,Ho,Wo,Cout) with w (Cout,R,S,Cin) [+ residual].  bf16 / fp16 dy and w:
+    native 16-bit operands, dx (and the residual) in that type."""
     Nb, Ho, Wo, Cout = dy.shape
     _, R, S, Cin = w.shape
     H, W = in_hw
-    assert dy.is_contiguous() and w.is_contiguous()
-    dx = out if out is not None else empty(Nb, H, W, Cin, device=dy.device)
+    assert dy.is_contiguous() and w.is_contiguous() and dy.dtype == w.dtype
+    h16 = _h16(dy)
+    dx = out if out is not None else torch.empty(Nb, H, W, Cin, dtype=dy.dtype, device=dy.device)
+    io = dict(h16=h16, io16=_io16(dx, residual, h16)) if h16 is not None else {}
     K = R * S * Cout
     if stride == 2 and H % 2 == 0 and W % 2 == 0:
         # 4 parity classes of input pixels, each a dense GEMM over the taps that can reach it (4x fewer MACs)
         gemm_raw(OP_CONV_DGRAD_S2, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), Nb * (H // 2) * (W // 2), Cin, K, 0, 0, Cin,
                  residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
-                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), **io)
         return dx
     if stride == 1 and _DGRAD_AS_FWD[0] and Cout % 32 == 0 and Cin % 4 == 0 and R - 1 - pad >= 0:
         # stride-1 data gradient = forward convolution over dY with flipped, channel-swapped weights (one small
         # transpose of the weight per call = per step): both GEMM operands are then k-contiguous, i.e. they take the
         # LDS-DMA kernel's ds_read_b128 path instead of the strided [k][n] weight view
-        wt = empty(Cin, R, S, Cout, device=dy.device)
-        check(_lib.lib().ick_conv_weight_dgrad_layout(w.data_ptr(), wt.data_ptr(), Cout, R, S, Cin, _st()),
-              "ick_conv_weight_dgrad_layout")
+        wt = wt_cached if wt_cached is not None else conv_weight_dgrad_layout(w)
         gemm_raw(OP_CONV_FWD, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, K, K, Cin,
                  residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
-                 conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad))
+                 conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad), **io)
         return dx
     gemm_raw(OP_CONV_DGRAD, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, 0, 0, Cin,
              residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
-             conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+             conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), **io)
     return dx
 
 
+def conv_weight_dgrad_layout(w: torch.Tensor) -> torch.Tensor:
+    """wt[ci][R-1-r][S-1-s][co] = w[co][r][s][ci] (fp32, bf16 or fp16)."""
+    Cout, R, S, Cin = w.shape
+    wt = torch.empty(Cin, R, S, Cout, dtype=w.dtype, device=w.device)
+    if w.dtype == _F32:
+        check(_lib.lib().ick_conv_weight_dgrad_layout(w.data_ptr(), wt.data_ptr(), Cout, R, S, Cin, _st()), "ick_conv_weight_dgrad_layout")
+    else:
+        check(_lib.lib().ick_conv_weight_dgrad_layout16(w.data_ptr(), wt.data_ptr(), Cout, R, S, Cin, _st()), "ick_conv_weight_dgrad_layout16")
+    return wt
+
+
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int, pad: int, splitk: int = 0) -> None:
-    """dw (Cout,R,S,Cin) += sum over output pixels of dy (x) gathered x (accumulates, fp32 atomics when split)."""
+    """dw (Cout,R,S,Cin) += sum over output pixels of dy (x) gathered x (accumulates, fp32 atomics when split); dw is fp32,
+    dy and x fp32 or both bf16 / fp16 (native 16-bit operands)."""
     Nb, Ho, Wo, Cout = dy.shape
     _, H, W, Cin = x.shape
     _, R, S, _ = dw.shape
-    assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous()
+    assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous() and dy.dtype == x.dtype and dw.dtype == _F32
+    io = dict(h16=_h16(dy)) if _h16(dy) is not None else {}
     K = Nb * Ho * Wo
     N = R * S * Cin
     if splitk <= 0:
@@ -413,10 +451,10 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int,
         splitk = max(1, min(64, 768 // max(tiles, 1), K // 128))
     if splitk > 1:
         gemm_raw(OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, splitk=splitk,
-                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), **io)
     else:
         gemm_raw(OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, accumulate=True,
-                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), **io)
 
 
 # ----------------------------------------------------------------------------- BatchNorm pieces
@@ -459,11 +497,21 @@ def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batc
     if sums is None:
         sums = torch.zeros(2, BN_BWD_COPIES, C, dtype=torch.float64, device=x.device)
     R = sums.shape[1] if sums.dim() == 3 else 1
-    check(_lib.lib().ick_bn_bwd_reduce(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                                       sums[0].data_ptr(), sums[1].data_ptr(), R, C, M, C, act, _st()), "ick_bn_bwd_reduce")
     dx = torch.empty_like(x)
     g = torch.empty_like(x) if want_g else None
     coef = empty(2, C, device=x.device)
+    if x.dtype in _H16:        # 16-bit activation storage (dy, y, x, dx, g all of one 16-bit type)
+        assert dy.dtype == x.dtype and (y_mask is None or y_mask.dtype == x.dtype)
+        f16 = int(x.dtype == torch.float16)
+        check(_lib.lib().ick_bn_bwd_reduce16(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                             sums[0].data_ptr(), sums[1].data_ptr(), R, C, M, C, act, f16, _st()), "ick_bn_bwd_reduce16")
+        check(_lib.lib().ick_bn_bwd_apply16(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                            gamma.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), R, C, coef.data_ptr(),
+                                            dx.data_ptr(), _ptr(g), M, C, int(batch_stats), _ptr(dgamma), _ptr(dbeta), act, f16, _st()),
+              "ick_bn_bwd_apply16")
+        return dx, g
+    check(_lib.lib().ick_bn_bwd_reduce(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                       sums[0].data_ptr(), sums[1].data_ptr(), R, C, M, C, act, _st()), "ick_bn_bwd_reduce")
     check(_lib.lib().ick_bn_bwd_apply(dy.data_ptr(), _ptr(y_mask), x.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
                                       gamma.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(), R, C, coef.data_ptr(),
                                       dx.data_ptr(), _ptr(g),
@@ -478,6 +526,13 @@ def bn_train_apply(raw, stats, gamma, beta, rmean, rvar, momentum, eps, residual
     y = torch.empty_like(raw)
     sv = empty(2, C, device=raw.device)
     copies = stats[0].shape[0] if stats[0].dim() == 2 else 1
+    if raw.dtype in _H16:      # 16-bit activation storage
+        assert residual is None or residual.dtype == raw.dtype
+        check(_lib.lib().ick_bn_train_apply16(raw.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), copies, C, gamma.data_ptr(),
+                                              beta.data_ptr(), _ptr(rmean), _ptr(rvar), momentum, eps, _ptr(residual), y.data_ptr(),
+                                              sv[0].data_ptr(), sv[1].data_ptr(), raw.numel() // C, C, int(relu),
+                                              int(raw.dtype == torch.float16), _st()), "ick_bn_train_apply16")
+        return y, sv[0], sv[1]
     check(_lib.lib().ick_bn_train_apply(raw.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(), copies, C, gamma.data_ptr(),
                                         beta.data_ptr(), _ptr(rmean), _ptr(rvar), momentum, eps, _ptr(residual), y.data_ptr(),
                                         sv[0].data_ptr(), sv[1].data_ptr(), raw.numel() // C, C, int(relu), _st()),
@@ -530,7 +585,10 @@ def dot_attn_bwd(dx_t, w_t, hp, feats, dfeats, dhp) -> None:
 def maxpool3x3s2(x):
     Nb, H, W, C = x.shape
     Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
-    y = empty(Nb, Ho, Wo, C, device=x.device)
+    y = torch.empty(Nb, Ho, Wo, C, dtype=x.dtype, device=x.device)
+    if x.dtype in _H16:
+        check(_lib.lib().ick_maxpool3x3s2_16(x.data_ptr(), y.data_ptr(), Nb, H, W, C, int(x.dtype == torch.float16), _st()), "ick_maxpool3x3s2_16")
+        return y
     check(_lib.lib().ick_maxpool3x3s2(x.data_ptr(), y.data_ptr(), Nb, H, W, C, _st()), "ick_maxpool3x3s2")
     return y
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ICK_ABI_VERSION 3
+#define ICK_ABI_VERSION 4
 
 const char* ick_last_error(void);
 int ick_abi_version(void);
@@ -74,6 +74,7 @@ typedef struct IckGemm {
   int64_t stat_stride;                          /* elements between two copies (>= N) */
   const float* col_scale;                       /* [N] or NULL: C = act(col_scale[n] * alpha*sum + bias[n] ...) — eval-mode BatchNorm folded into the conv epilogue (scale = gamma/sqrt(var+eps), bias = shift); needs N %% 4, ldc %% 4, no split-K */
   int32_t kchunk;                               /* fp32 kernels: k elements one MFMA accumulator chain sums before it is folded into a master accumulator (bounds the rounding error of long-K products the way a K-blocked CPU GEMM does); 0 = library default (64), < 0 = one chain over all of K */
+  int32_t io16;                                 /* ick_gemm_h16 only (0 elsewhere): bit 0 = C holds 16-bit elements of the operand type (also what `accumulate` reads), bit 1 = the residual does; both need the vector epilogue (N %% 4, ldc %% 4, ldr %% 4, no split-K) */
 } IckGemm;
 
 int ick_gemm_f32(const IckGemm* desc, void* stream);
@@ -84,14 +85,20 @@ int ick_gemm_f32(const IckGemm* desc, void* stream);
  * terms = 1: plain bf16 products; terms = 2: fp16 products (v_mfma_f32_32x32x16_f16 — the reference's autocast dtype: 10
  * mantissa bits, 5-bit exponent, to be run under the loss scaler); terms = 3: each operand split into hi + lo bf16 parts and
  * hi*hi + hi*lo + lo*hi accumulated (~1e-5 relative to the exact fp32 product, 3 MFMAs per k-step).
+ * IckGemm.io16 (terms 1 / 2, shapes the LDS-DMA kernel takes): C / the residual stored as bf16 / fp16 — the 4-channel stem
+ * convolution of the 16-bit training regime reads fp32 images and writes 16-bit activations this way.
  * Convolutions whose channel count is not a multiple of 32 run on the exact-fp32 kernel. */
 int ick_gemm_bf16(const IckGemm* desc, int terms, void* stream);
-/* NATIVE 16-bit operands: A [M][K] and B [N][K] hold bf16 (fp16 = 0) or fp16 (fp16 = 1) elements in HBM — the storage the
- * reference's autocast keeps (train_student_kd.py:271); fp32 accumulation, fp32 C and epilogues as above.  ICK_OP_NT and
- * ICK_OP_CONV_FWD only (both operands k-contiguous); M, N, K, lda, ldb and the conv geometry are in ELEMENTS; K, lda, ldb
- * multiples of 8, Cin a multiple of 64; no batching / split-K.  ick_cast_f32_to_16 produces such operands (n % 4 == 0). */
+/* NATIVE 16-bit operands: A and B hold bf16 (fp16 = 0) or fp16 (fp16 = 1) elements in HBM and in LDS — the storage the
+ * reference's autocast keeps its activations and weight copies in (train_student_kd.py:271); fp32 accumulation, fp32
+ * bias / statistics / epilogue arithmetic; C and the residual are fp32 or (IckGemm.io16) 16-bit.  Every op of the family;
+ * all extents, leading dimensions and the conv geometry are in ELEMENTS and follow ick_gemm_bf16's rules (multiples of 4;
+ * conv channel counts multiples of 32); no split-K into a 16-bit C.  Operands whose k index is contiguous (NT, CONV_FWD) with
+ * K, lda, ldb multiples of 8 and Cin a multiple of 64 run on the LDS-DMA kernel (one ds_read_b128 = one MFMA operand); the
+ * others on the register-staged kernel (transposed LDS reads).  ick_cast_f32_to_16 / ick_cast_16_to_f32: n %% 4 == 0. */
 int ick_gemm_h16(const IckGemm* desc, int fp16, void* stream);
 int ick_cast_f32_to_16(const float* x, void* y, int64_t n, int fp16, void* stream);
+int ick_cast_16_to_f32(const void* x, float* y, int64_t n, int fp16, void* stream);
 
 /* ------------------------------------------------------------------ fused attention forward (head dim 64)
  * softmax(Q K^T * scale [causal]) V per (batch, head) without materialising the scores: timm ViT-S/16 self-attention
@@ -108,6 +115,7 @@ int ick_nchw3_to_nhwc4(const float* x, float* y, int B, int H, int W, void* stre
 int ick_nhwc4_to_nhwc3_add(const float* src4, float* dst3, int64_t npix, void* stream);      /* dst3[p][c] += src4[p][c], c < 3 */
 int ick_patchify16(const float* x, float* y, int B, int HW, void* stream);                /* -> [B*(HW/16)^2][768], k=(c,py,px): timm PatchEmbed as a GEMM */
 int ick_conv_weight_dgrad_layout(const float* w, float* wt, int Cout, int R, int S, int Cin, void* stream); /* wt[ci][R-1-r][S-1-s][co] = w[co][r][s][ci]: with it the stride-1 data gradient of a convolution (autograd of student_model.py:57 through layer3/layer4) is a forward convolution over dY with pad R-1-pad, both GEMM operands k-contiguous */
+int ick_conv_weight_dgrad_layout16(const void* w, void* wt, int Cout, int R, int S, int Cin, void* stream);   /* the same on 16-bit elements (bf16 or fp16) */
 int ick_vit_assemble(const float* patch, const float* cls, const float* pos, float* x, int B, int Ntok, int D, void* stream); /* cls token + pos_embed (timm forward_features) */
 
 /* ------------------------------------------------------------------ input transform, bit-exact with Pillow
@@ -134,13 +142,22 @@ int ick_scale_shift_act(const float* x, const float* scale, const float* shift, 
                         int64_t M, int C, int relu, void* stream);                          /* y = [relu](x*scale+shift [+ residual]) */
 int ick_bn_bwd_reduce(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                       double* sum_g, double* sum_gx, int copies, int64_t stride, int64_t M, int C, int act /* mask of y: 1 = ReLU (y > 0), 2 = ReLU6 (0 < y < 6) */, void* stream); /* += sum(g), sum(g*xhat) in fp64, spread over `copies` accumulator rows `stride` elements apart (row-block b adds into row b %% copies; ick_bn_bwd_apply folds them) (the reference's CPU batch_norm backward reduces in double); g = dy*(y>0) if y */
+int ick_bn_bwd_reduce16(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                        double* sum_g, double* sum_gx, int copies, int64_t stride, int64_t M, int C, int act, int fp16, void* stream);  /* dy, y, x stored as bf16 (fp16 = 0) / fp16 (1): the 16-bit training regime */
 int ick_bn_bwd_apply(const float* dy, const float* y, const float* x, const float* mean, const float* invstd,
                      const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws /* [2*C] scratch */,
                      float* dx, float* g_out, int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, int act /* as in ick_bn_bwd_reduce */, void* stream); /* dgamma/dbeta (optional) += the two sums */
+int ick_bn_bwd_apply16(const void* dy, const void* y, const void* x, const float* mean, const float* invstd,
+                       const float* gamma, const double* sum_g, const double* sum_gx, int copies, int64_t stride, float* coef_ws,
+                       void* dx, void* g_out, int64_t M, int C, int use_batch_stats, float* dgamma, float* dbeta, int act, int fp16, void* stream);  /* 16-bit dy, y, x, dx, g_out */
 int ick_bn_train_apply(const float* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
                        float* running_mean, float* running_var, float momentum, float eps, const float* residual,
                        float* y, float* save_mean, float* save_invstd, int64_t M, int C, int relu, void* stream); /* bn_finalize + scale_shift_act in one pass */
+int ick_bn_train_apply16(const void* x, const double* sum, const double* sq, int stat_copies, int64_t stat_stride, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps, const void* residual,
+                         void* y, float* save_mean, float* save_invstd, int64_t M, int C, int relu, int fp16, void* stream);  /* 16-bit x, residual, y; statistics and parameters fp32 / fp64 as above */
 int ick_maxpool3x3s2(const float* x, float* y, int B, int H, int W, int C, void* stream); /* nn.MaxPool2d(3,2,1), NHWC */
+int ick_maxpool3x3s2_16(const void* x, void* y, int B, int H, int W, int C, int fp16, void* stream);   /* 16-bit activations */
 int ick_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int H, int W, int C, void* stream); /* its adjoint (first maximum of a window takes the gradient): only CNNEncoder(fine_tune=False) trains below layer3 */
 int ick_adaptive_avgpool_fwd(const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo, void* stream); /* nn.AdaptiveAvgPool2d((7,7)) (student_model.py:34,60) on NHWC: the identity at 224x224 inputs, real pooling otherwise */
 int ick_adaptive_avgpool_bwd(const float* dy, float* dx, int B, int H, int W, int C, int Ho, int Wo, void* stream);
