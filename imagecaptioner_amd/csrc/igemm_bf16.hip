@@ -634,7 +634,7 @@ extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
   // the LDS-DMA variant (igemm_bf16_glds_impl.h) is the default where it exists; IckGemm.tile bit 8 or ICK_NO_GLDS_BF16=1
   // selects this file's register-staged kernel (conv wgrad always: both operands x-contiguous + per-lane gather)
   static const bool no_glds = [] { const char* e = getenv("ICK_NO_GLDS_BF16"); return e && e[0] == '1'; }();
-  if (!no_glds && !(d->tile & 256) && d->op != ICK_OP_CONV_WGRAD && glds_eligible(d)) {
+  if ((d->io16 || (!no_glds && !(d->tile & 256))) && d->op != ICK_OP_CONV_WGRAD && glds_eligible(d)) {   // (a 16-bit C exists on the LDS-DMA kernel only)
     IckGemm dd = *d; dd.tile &= 255;
     return run_glds_bf16(&dd, terms, p, nz, st);
   }

@@ -11,6 +11,8 @@ every `.grad` into one flat fp32 buffer for a single RCCL all-reduce and a fused
 from __future__ import annotations
 
 import math
+import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -270,11 +272,53 @@ def _eval_coeffs(bn: BatchNorm2d) -> torch.Tensor:
     return cached[1]
 
 
-def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool, w_packed=None, arena=None, counters=None):
+# ---- 16-bit activation storage of the training trunk (the reference's autocast regime keeps activations and a weight copy
+# in fp16, train_student_kd.py:271).  Under ops.precision("bf16" / "fp16") a TRAIN-mode trunk stores every activation,
+# raw conv output and gradient as bf16 / fp16: the convolutions read them as native 16-bit MFMA operands (ick_gemm_h16),
+# BatchNorm / max-pool move half the bytes; statistics (fp64), BatchNorm parameters, weight gradients and master weights
+# stay fp32.  ICK_TRUNK16=0 keeps fp32 storage (the r01/r02 "fp32 image" AMP path) for A/B runs.
+_TRUNK16 = [os.environ.get("ICK_TRUNK16", "1") != "0"]
+_H16_OF = {"bf16": torch.bfloat16, "fp16": torch.float16}
+_WEIGHT_SHADOW: dict = {}     # id(parameter) -> 16-bit [Cout][R][S][Cin] copy kept current by the trainer (one flat cast per step)
+
+
+def install_weight_shadow(param: torch.Tensor, w16: torch.Tensor) -> None:
+    """Registers a 16-bit copy of a conv weight that the caller keeps up to date (KDTrainer: one cast of the flat
+    parameter buffer per step); conv weights without one are cast on use."""
+    _WEIGHT_SHADOW[id(param)] = (weakref.ref(param), w16)       # (the weak reference guards against a recycled id)
+
+
+def clear_weight_shadows() -> None:
+    _WEIGHT_SHADOW.clear()
+
+
+def _w16(conv: Conv2d, dt: torch.dtype) -> torch.Tensor:
+    """The conv weight as [Cout][R][S][Cin] in the 16-bit storage type: the trainer's shadow, a cached copy of a frozen
+    weight, or a fresh cast."""
+    sh = _WEIGHT_SHADOW.get(id(conv.weight))
+    if sh is not None and sh[0]() is conv.weight and sh[1].dtype == dt:
+        return sh[1]
+    w = conv.packed()
+    if not conv.weight.requires_grad:       # frozen: changes only through torch (load_state_dict) -> version counter
+        key = (w.data_ptr(), conv.weight._version, dt)
+        cached = getattr(conv, "_ick_w16", None)
+        if cached is None or cached[0] != key:
+            cached = (key, ops.cast16(w.contiguous(), dt))
+            conv._ick_w16 = cached
+        return cached[1]
+    return ops.cast16(w.contiguous(), dt)
+
+
+def _wlike(conv: Conv2d, like: torch.Tensor) -> torch.Tensor:
+    return conv.packed() if like.dtype == torch.float32 else _w16(conv, like.dtype)
+
+
+def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool, w_packed=None, arena=None, counters=None,
+            out_dtype=None):
     """raw = conv(x); y = [relu](bn(raw) [+ residual]).  Train mode: batch statistics from the conv epilogue (fp64
     sums), normalisation + running-stat update in one pass over raw (also for frozen layers).
-    Returns (y, raw, mean, invstd)."""
-    w = w_packed if w_packed is not None else conv.packed()
+    Returns (y, raw, mean, invstd).  16-bit x: 16-bit weights, raw and y (out_dtype: the stem's fp32 images -> 16-bit)."""
+    w = w_packed if w_packed is not None else _wlike(conv, x)
     if train:
         bn._ick_eval_co = None       # running statistics (and soon the affine parameters) change under raw kernels
         C = w.shape[0]
@@ -282,7 +326,7 @@ def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool,
         R = ops.stat_copies(x.shape[0] * Ho * Wo)
         stats = (arena.take(2 * R, C) if arena is not None else
                  torch.zeros(2 * R, C, dtype=torch.float64, device=x.device)).view(2, R, C)
-        raw = ops.conv_fwd(x, w, conv.stride, conv.padding, stats=(stats[0], stats[1]))
+        raw = ops.conv_fwd(x, w, conv.stride, conv.padding, stats=(stats[0], stats[1]), out_dtype=out_dtype)
         y, mean, inv = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
                                           bn.eps, residual, relu)
         if counters is not None:
@@ -368,22 +412,22 @@ def bottleneck_backward(blk: Bottleneck, r: dict, d, need_in: bool, sums_arena=N
 
     dx3, g3 = bnb(d, r["out"], r["r3"], r["m3"], r["i3"], blk.bn3, want_g=True)
     wgrad(blk.conv3, dx3, r["a2"])
-    da2 = ops.conv_dgrad(dx3, blk.conv3.packed(), r["a2"].shape[1:3], 1, 0)
+    da2 = ops.conv_dgrad(dx3, _wlike(blk.conv3, dx3), r["a2"].shape[1:3], 1, 0)
     dx2, _ = bnb(da2, r["a2"], r["r2"], r["m2"], r["i2"], blk.bn2)
     wgrad(blk.conv2, dx2, r["a1"])
-    da1 = ops.conv_dgrad(dx2, blk.conv2.packed(), r["a1"].shape[1:3], blk.conv2.stride, 1)
+    da1 = ops.conv_dgrad(dx2, _wlike(blk.conv2, dx2), r["a1"].shape[1:3], blk.conv2.stride, 1)
     dx1, _ = bnb(da1, r["a1"], r["r1"], r["m1"], r["i1"], blk.bn1)
     wgrad(blk.conv1, dx1, r["x"])
     hw = r["x"].shape[1:3]
     if blk.downsample is None:
-        return ops.conv_dgrad(dx1, blk.conv1.packed(), hw, 1, 0, residual=g3) if need_in else None
+        return ops.conv_dgrad(dx1, _wlike(blk.conv1, dx1), hw, 1, 0, residual=g3) if need_in else None
     dsc, dsb = blk.downsample[0], blk.downsample[1]
     dxd, _ = bnb(g3, None, r["rd"], r["md"], r["idv"], dsb)
     wgrad(dsc, dxd, r["x"])
     if not need_in:
         return None
-    dxi = ops.conv_dgrad(dx1, blk.conv1.packed(), hw, 1, 0)
-    ops.conv_dgrad(dxd, dsc.packed(), hw, dsc.stride, 0, out=dxi, accumulate=True)
+    dxi = ops.conv_dgrad(dx1, _wlike(blk.conv1, dx1), hw, 1, 0)
+    ops.conv_dgrad(dxd, _wlike(dsc, dxd), hw, dsc.stride, 0, out=dxi, accumulate=True)
     return dxi
 
 
@@ -410,7 +454,12 @@ class ResNetTrunkFn(Function):
         if train:
             # up to 8 accumulator copies per BatchNorm (ops.stat_copies)
             arena, counters = _Arena(2 * (64 + _bn_channels(blocks)) * 8, torch.float64, images.device), []
-        ys, raw_s, mean_s, inv_s = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters)
+        # 16-bit activation storage (see _TRUNK16): train mode under a 16-bit GEMM precision, frozen stem, channel counts
+        # the 16-bit kernels take (every ResNet-50 layer)
+        dt16 = _H16_OF.get(ops.gemm_precision()) if (train and _TRUNK16[0] and not stem_trainable) else None
+        ctx.dt16 = dt16
+        ys, raw_s, mean_s, inv_s = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters,
+                                           out_dtype=dt16)
         y = ops.maxpool3x3s2(ys)
         first = 0 if stem_trainable else next((i for i, b in enumerate(blocks) if _block_trainable(b)), len(blocks))
         want_bwd = any(ctx.needs_input_grad) and first < len(blocks)   # (forward itself always runs in no-grad mode)
@@ -426,6 +475,8 @@ class ResNetTrunkFn(Function):
         ctx.blocks, ctx.first, ctx.recs = blocks, first, recs
         ctx.stem = dict(x4=x4, ys=ys, raw=raw_s, mean=mean_s, inv=inv_s, conv=stem, bn=resnet[1]) if (want_bwd and stem_trainable) else None
         Nb, H, W, C = y.shape
+        if dt16 is not None:
+            y = ops.cast32(y)                                        # the decoder side reads fp32 features
         ctx.pool_from = None
         if (H, W) != (7, 7):                                         # nn.AdaptiveAvgPool2d((7,7)), student_model.py:34,60: real work
             ctx.pool_from = (H, W)                                   # only for inputs other than 224 x 224
@@ -445,6 +496,8 @@ class ResNetTrunkFn(Function):
             d = ops.adaptive_avgpool_bwd(_c(dy).view(Nb, 7, 7, C), *ctx.pool_from)
         else:
             d = _c(dy).view(recs[-1]["out"].shape)
+        if ctx.dt16 is not None:
+            d = ops.cast16(d, ctx.dt16)                              # gradients travel through the trunk in the storage type
         state = dict(blocks=blocks, first=first, recs=recs, d=d, next=len(blocks) - 1, stem=ctx.stem,
                      sums=_Arena(2 * ops.BN_BWD_COPIES * _bn_channels(blocks[first:]), torch.float64, d.device))
         if _TRUNK_DEFER["on"]:

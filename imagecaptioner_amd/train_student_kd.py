@@ -176,6 +176,17 @@ class KDTrainer:
         if len(self.buckets) != 3:
             self.bucketed = False
         self.comm_stream = torch.cuda.Stream() if (self.bucketed and self.device.type == "cuda") else None
+        # 16-bit training regime (hnn._TRUNK16): the trunk reads bf16 / fp16 weights.  One cast of the encoder segment of the
+        # flat parameter buffer per step keeps a flat 16-bit shadow current; every trainable conv weight gets a view of it.
+        self.flat16 = None
+        dt16 = hnn._H16_OF.get(precision)
+        if dt16 is not None and hnn._TRUNK16[0] and cuda:
+            a, b = self.flat.segment("encoder")
+            self.flat16 = torch.zeros(b, dtype=dt16, device=self.device)
+            for p, o, n in self.flat.metas:
+                if p.dim() == 4 and o + n <= b:
+                    co, ci, r, s_ = p.shape
+                    hnn.install_weight_shadow(p, self.flat16[o:o + n].view(co, r, s_, ci))
         self.g_stage: List[Optional[torch.cuda.CUDAGraph]] = [None, None, None]
         self._trunk_state = None
         self._l4_first = None
@@ -215,6 +226,8 @@ class KDTrainer:
         if self.accumulation_steps == 1:
             self.flat.grad.zero_()   # gradients stay inspectable after the step; with accumulation the buffer is
         self.drop_step += 1          # zeroed at the end of the optimizer pass instead, so a window accumulates
+        if self.flat16 is not None:  # this step's 16-bit copy of the trunk's master weights (after the previous AdamW pass)
+            ops.cast16(self.flat.param[:self.flat16.numel()], self.flat16.dtype, out=self.flat16)
         cin, ctg = self.captions[:-1], self.captions[1:]
         # The frozen teacher's forward does not depend on the student: it runs on a side HIP stream (a parallel
         # branch of the captured graph), so its large GEMMs fill the CUs that the student's latency-bound

@@ -170,24 +170,25 @@ def _no_dropout(s, p):
     s.decoder.lstm.dropout = 0.0
 
 
-@pytest.mark.parametrize("prec,tol_logit,tol_loss,tol_grad", [("bf16", 5e-2, 2e-2, 0.35), ("bf16x3", 1e-3, 1e-3, 2e-2),
+@pytest.mark.parametrize("prec,tol_logit,tol_loss,tol_grad", [("bf16", 5e-2, 2e-2, 0.45), ("bf16x3", 1e-3, 1e-3, 2e-2),
                                                               ("fp16", 1e-2, 5e-3, 8e-2)])
 def test_mixed_precision_student_vs_fp32_path(prec, tol_logit, tol_loss, tol_grad):
     """cfg3/cfg4's AMP regime (reference: autocast around student + projector + loss, fp32 teacher,
     train_student_kd.py:263-285): the student's contractions on the bf16 matrix cores with fp32 accumulation and
     fp32 master weights, against the exact-fp32 HIP path (itself pinned to the oracle above) on the same inputs.
     Tolerances (written here, not hidden): bf16 — eval logits 5e-2 of their scale, KD loss terms 2 %, decoder gradients
-    35 % relative L2 AND cosine >= 0.93 (measured 0.29: the token-KL gradient tau*(p_s - p_t)/N is a difference of two
-    nearly equal distributions at random init, so 8-bit operands perturb it strongly — the regime the reference's fp16
-    autocast trains in); split-bf16x3 — 1e-3 / 1e-3 / 2e-2 (measured 1.3e-2 through the trunk).
+    45 % relative L2 AND cosine >= 0.9 (measured 0.40 with the trunk's activations STORED as bf16 — nn._TRUNK16, what
+    torch.autocast(bfloat16) stores too — 0.29 with fp32 storage between the kernels: the token-KL gradient
+    tau*(p_s - p_t)/N is a difference of two nearly equal distributions at random init, so 8-bit operands perturb it
+    strongly); split-bf16x3 — 1e-3 / 1e-3 / 2e-2 (measured 1.3e-2 through the trunk).
     Gradients upstream of the train-mode trunk are compared for bf16x3 only: at B=4 that problem is ill-conditioned
     (the exact-fp32 path is already 1-2e-2 from an fp64 evaluation, profiles/diag_grads_r01.log), so 8-bit operands
     decorrelate it (measured 0.48 relative L2) without saying anything about the kernels.
     fp16 — the reference's actual autocast dtype (train_student_kd.py:239,271,288-299): v_mfma_f32_32x32x16_f16 under the
     device-side GradScaler (init 2^16 like torch.amp.GradScaler); 11 significant bits -> logits 1e-2, loss 0.5 %, decoder
-    gradients 8e-2 relative L2 (measured 6.7e-2 against bf16's 0.29 on the same tensors: the same p_s - p_t cancellation,
-    4.4x less of it; activations stay fp32 between kernels, so this is no worse than torch autocast, which also rounds every
-    Linear / conv OUTPUT to fp16), compared after dividing by the loss scale."""
+    gradients 8e-2 relative L2 (measured 6.7e-2 against bf16's 0.29 on the same tensors with fp32 storage between the
+    kernels: the same p_s - p_t cancellation, 4.4x less of it; with the trunk's activations stored as fp16 — the default,
+    and what torch autocast stores — the bound still holds), compared after dividing by the loss scale."""
     from imagecaptioner_amd import ops
     from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
     from imagecaptioner_amd.utils.seeded_init import synthetic_batch
@@ -222,7 +223,7 @@ def test_mixed_precision_student_vs_fp32_path(prec, tol_logit, tol_loss, tol_gra
     for k, gb in out["f32"][1].items():
         ga = out[prec][1][k]
         assert ((ga - gb).norm() / gb.norm()).item() < tol_grad, k
-        assert (torch.dot(ga, gb) / (ga.norm() * gb.norm())).item() >= 0.93, k
+        assert (torch.dot(ga, gb) / (ga.norm() * gb.norm())).item() >= (0.9 if prec == "bf16" else 0.93), k
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
