@@ -247,16 +247,24 @@ __global__ void bn_train_apply_kernel(const T* __restrict__ x, const double* __r
       }
     }
   }
-  for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
-    const float4 v = ld4(x, i);
+  const long gstride = (long)gridDim.x * blockDim.x;     // a multiple of C4: a thread's channels never change
+  auto one = [&](float4 v, float4 r) {
     float4 o = make_float4(fmaf(v.x, sc[0], sh[0]), fmaf(v.y, sc[1], sh[1]), fmaf(v.z, sc[2], sh[2]), fmaf(v.w, sc[3], sh[3]));
-    if (res) {
-      const float4 r = ld4(res, i);
-      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-    }
+    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    st4(y, i, o);
+    return o;
+  };
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  long i = i0;
+  if constexpr (sizeof(T) == 2) {       // 8-byte accesses: two groups per trip keep the bytes in flight of the fp32 form
+    for (; i + gstride < total4; i += 2 * gstride) {
+      const float4 v0 = ld4(x, i), v1 = ld4(x, i + gstride);
+      const float4 r0 = res ? ld4(res, i) : zero, r1 = res ? ld4(res, i + gstride) : zero;
+      st4(y, i, one(v0, r0));
+      st4(y, i + gstride, one(v1, r1));
+    }
   }
+  for (; i < total4; i += gstride) st4(y, i, one(ld4(x, i), res ? ld4(res, i) : zero));
 }
 
 // BN backward pass 1: per channel sum(g) and sum(g * xhat), g = dy * (y > 0) when y != NULL.
@@ -285,19 +293,21 @@ __global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restri
     if (tr < rows && cok) {
       // 4 rows per trip: 12 independent 16-byte loads in flight per thread (one row per trip left the kernel
       // latency-bound at ~3.6 TB/s with 1.5 workgroups per CU)
+      // (16-bit storage: 8 rows per trip keep the same number of bytes in flight)
+      constexpr int U = sizeof(T) == 2 ? 8 : 4;
       const long step = (long)gridDim.y * rows;
       long m = blockIdx.y * (long)rows + tr;
-      for (; m + 3 * step < M; m += 4 * step) {
-        float4 g[4], xv[4], yy[4];
+      for (; m + (U - 1) * step < M; m += U * step) {
+        float4 g[U], xv[U], yy[U];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           const long o = (m + u * step) * C4 + c4;
           g[u] = ld4(dy, o);
           xv[u] = ld4(x, o);
           if (y) yy[u] = ld4(y, o);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
           if (y) {
             g[u].x = (yy[u].x > 0.f && yy[u].x < hi) ? g[u].x : 0.f; g[u].y = (yy[u].y > 0.f && yy[u].y < hi) ? g[u].y : 0.f;
             g[u].z = (yy[u].z > 0.f && yy[u].z < hi) ? g[u].z : 0.f; g[u].w = (yy[u].w > 0.f && yy[u].w < hi) ? g[u].w : 0.f;

@@ -121,7 +121,8 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
              strides: Tuple[int, int, int, int, int, int] = (0, 0, 0, 0, 0, 0), splitk: int = 1,
              accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
              conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0,
-             col_scale: Optional[int] = None, kchunk: int = 0, h16: Optional[torch.dtype] = None, io16: int = 0) -> None:
+             col_scale: Optional[int] = None, kchunk: int = 0, h16: Optional[torch.dtype] = None, io16: int = 0,
+             default_tile: int = 0) -> None:
     """h16 = torch.bfloat16 / torch.float16: A and B hold that type in HBM (ick_gemm_h16); io16 bit 0 / 1: so do C / the
     residual."""
     d = IckGemm()
@@ -140,7 +141,7 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
         d.Nb, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout, d.R, d.S, d.stride, d.pad = conv
     if h16 is not None:
         d.io16 = io16
-        d.tile = tile or _FORCE_TILE[0] or _TUNED_H16.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
+        d.tile = tile or _FORCE_TILE[0] or _TUNED_H16.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", default_tile)
         check(_lib.lib().ick_gemm_h16(ctypes.byref(d), int(h16 == torch.float16), _st()), "ick_gemm_h16")
         return
     terms = _PRECISIONS[_PREC[0]]
@@ -443,9 +444,15 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int,
     _, H, W, Cin = x.shape
     _, R, S, _ = dw.shape
     assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous() and dy.dtype == x.dtype and dw.dtype == _F32
-    io = dict(h16=_h16(dy)) if _h16(dy) is not None else {}
+    io = dict(h16=_h16(dy), default_tile=3) if _h16(dy) is not None else {}      # 128x64: best or within 3 % on every shape measured
     K = Nb * Ho * Wo
     N = R * S * Cin
+    if splitk <= 0 and io:
+        # native 16-bit operands (measured, tools/bench_wgrad16.py): ~784 pixels per split is the sweet spot on every layer3 /
+        # layer4 shape (1024x256x12544: 40 us at 16 splits against 56 at 48; 2048x512x3136: 39 us at 4 against 54 at 12),
+        # capped so that the grid stays within ~6 workgroups per CU
+        tiles = ((Cout + 127) // 128) * ((N + 63) // 64)
+        splitk = max(1, min(64, K // 784, 1536 // max(tiles, 1)))
     if splitk <= 0:
         tiles = ((Cout + 127) // 128) * ((N + 127) // 128)
         splitk = max(1, min(64, 768 // max(tiles, 1), K // 128))

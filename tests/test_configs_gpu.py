@@ -171,7 +171,7 @@ def _no_dropout(s, p):
 
 
 @pytest.mark.parametrize("prec,tol_logit,tol_loss,tol_grad", [("bf16", 5e-2, 2e-2, 0.45), ("bf16x3", 1e-3, 1e-3, 2e-2),
-                                                              ("fp16", 1e-2, 5e-3, 8e-2)])
+                                                              ("fp16", 1e-2, 5e-3, 0.25)])
 def test_mixed_precision_student_vs_fp32_path(prec, tol_logit, tol_loss, tol_grad):
     """cfg3/cfg4's AMP regime (reference: autocast around student + projector + loss, fp32 teacher,
     train_student_kd.py:263-285): the student's contractions on the bf16 matrix cores with fp32 accumulation and
@@ -186,9 +186,11 @@ def test_mixed_precision_student_vs_fp32_path(prec, tol_logit, tol_loss, tol_gra
     decorrelate it (measured 0.48 relative L2) without saying anything about the kernels.
     fp16 — the reference's actual autocast dtype (train_student_kd.py:239,271,288-299): v_mfma_f32_32x32x16_f16 under the
     device-side GradScaler (init 2^16 like torch.amp.GradScaler); 11 significant bits -> logits 1e-2, loss 0.5 %, decoder
-    gradients 8e-2 relative L2 (measured 6.7e-2 against bf16's 0.29 on the same tensors with fp32 storage between the
-    kernels: the same p_s - p_t cancellation, 4.4x less of it; with the trunk's activations stored as fp16 — the default,
-    and what torch autocast stores — the bound still holds), compared after dividing by the loss scale."""
+    gradients 25 % relative L2 and cosine >= 0.93, compared after dividing by the loss scale.  Measured at this B = 4: 0.18
+    with the trunk's activations stored as fp16 (nn._TRUNK16, the default — what torch autocast stores too), 0.067 with
+    fp32 storage between the kernels; at B = 8 both storage regimes give 0.14 (tools/diag_trunk16.py): the same
+    p_s - p_t cancellation as bf16, driven by how far the encoder features move, and instance-dependent at these batch
+    sizes.  The kernels themselves are held to one rounding of the fp64 result in tests/test_h16_gpu.py."""
     from imagecaptioner_amd import ops
     from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
     from imagecaptioner_amd.utils.seeded_init import synthetic_batch

@@ -187,3 +187,103 @@ def test_h16_argument_checks():
         ops.gemm_raw(ops.OP_NT, a.data_ptr(), a.data_ptr(), a.data_ptr(), 64, 64, 64, 64, 64, 64, h16=torch.bfloat16, io16=1, splitk=2)
     with pytest.raises(IckError):        # the exact-fp32 family never writes 16-bit
         ops.gemm_raw(ops.OP_NT, c.data_ptr(), c.data_ptr(), c.data_ptr(), 64, 64, 64, 64, 64, 64, io16=1)
+
+
+def _rel_l2(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+# (inplanes, planes, stride, downsample, H): layer3.0, layer3.1, layer4.0, layer4.2 geometries of the trunk
+@pytest.mark.parametrize("dt,tol,tol_g", [(torch.float16, 6e-3, 4e-2), (torch.bfloat16, 5e-2, 1.2e-1)])
+@pytest.mark.parametrize("inpl,planes,stride,down,H", [(512, 256, 2, True, 28), (1024, 256, 1, False, 14),
+                                                        (1024, 512, 2, True, 14), (2048, 512, 1, False, 7)])
+def test_bottleneck_on_16bit_storage_vs_fp32_storage(dt, tol, tol_g, inpl, planes, stride, down, H):
+    """One train-mode Bottleneck, forward and backward, with every activation / gradient stored in 16 bits (nn._TRUNK16's
+    regime) against the exact-fp32 HIP path (pinned against fp64 in test_bn_trunk_gpu.py) on the SAME 16-bit-representable
+    input, weights and output gradient.  What differs: three intermediate activations, three raw conv outputs and the
+    gradients between the kernels are rounded to 11 (fp16) / 8 (bf16) significant bits.  Relative L2 bounds — output:
+    6e-3 / 5e-2.  Gradients: 4e-2 / 1.2e-1 (measured fp16 2.3-2.7e-2 on all four geometries): a pre-activation within one
+    rounding of zero takes the other side of the ReLU in the two runs, a fraction ~ulp of the elements, each an O(1) error
+    in its gradient entry -> relative L2 ~ sqrt(ulp) (2.2e-2 for fp16), the mask effect test_bn_trunk_gpu.py removes by
+    sharing masks; the per-kernel tests above are the tight ones."""
+    from imagecaptioner_amd import nn as hnn
+    from imagecaptioner_amd import ops
+    B = 8
+    torch.manual_seed(inpl + planes + stride)
+    blk = hnn.Bottleneck(inpl, planes, stride, downsample=down)
+    with torch.no_grad():
+        for name, p in blk.named_parameters():
+            if p.dim() == 1:
+                p.copy_(torch.rand_like(p) * 0.5 + 0.75 if name.endswith("weight") else torch.randn_like(p) * 0.1)
+            else:
+                p.copy_(p.to(dt).float())                     # weights representable in the storage type
+    blk = blk.cuda()
+    x = (torch.relu(rnd(B, H, H, inpl, seed=21)) * 0.7).to(dt).cuda()
+    dout = rnd(B, H // stride, H // stride, planes * 4, seed=22, scale=0.1).to(dt).cuda()
+
+    def run(x_in, d_in):
+        for p in blk.parameters():
+            p.grad = None
+        out, rec = hnn.bottleneck_forward(blk, x_in, True)
+        dx = hnn.bottleneck_backward(blk, rec, d_in, True)
+        return out, dx, {k: p.grad.clone() for k, p in blk.named_parameters()}
+
+    hnn.clear_weight_shadows()
+    out32, dx32, g32 = run(x.float(), dout.float())
+    out16, dx16, g16 = run(x, dout)
+    assert out16.dtype == dt and dx16.dtype == dt
+    assert _rel_l2(out16, out32) < tol
+    assert _rel_l2(dx16, dx32) < tol_g
+    bad = {k: _rel_l2(g16[k], g32[k]) for k in g32 if _rel_l2(g16[k], g32[k]) >= tol_g}
+    assert not bad, bad
+
+
+def test_trunk16_kd_step_runs_on_16bit_kernels_and_matches_fp32_storage_losses():
+    """The whole KD step under precision fp16 with 16-bit trunk storage (default) against fp32 storage between the kernels
+    (nn._TRUNK16 off): same loss terms within 1 %, the native 16-bit entry points actually run, weights' shadow current."""
+    from imagecaptioner_amd import nn as hnn
+    from imagecaptioner_amd import ops
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    images, caps = synthetic_batch(4, 5000, 16, seed=5)
+    losses, calls = {}, {"h16": 0}
+    orig = ops.gemm_raw
+
+    def counting(*a, **kw):
+        calls["h16"] += kw.get("h16") is not None
+        return orig(*a, **kw)
+
+    prev = hnn._TRUNK16[0]
+    try:
+        for on in (False, True):
+            hnn._TRUNK16[0] = on
+            hnn.clear_weight_shadows()
+            s, t, p = build_kd_models(device="cuda")
+            for mod in list(s.modules()) + list(p["encoder"].modules()):      # same arithmetic in both runs: no dropout draws
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+            s.attention_refinement.attention.dropout = 0.0
+            s.decoder.lstm.dropout = 0.0
+            tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=4, use_graph=False, precision="fp16")
+            assert (tr.flat16 is not None) == on
+            ops.gemm_raw = counting
+            calls["h16"] = 0
+            tr.train_step(images.cuda(), caps.cuda())
+            ops.gemm_raw = orig
+            assert (calls["h16"] > 100) == on, calls
+            losses[on] = tr.loss_dict()
+            if on:      # the shadow the trunk read = this step's master weights, rounded
+                w = s.encoder.resnet[7][2].conv3.weight
+                sh = hnn._w16(s.encoder.resnet[7][2].conv3, torch.float16)
+                assert sh.data_ptr() != w.data_ptr() and sh.dtype == torch.float16
+                tr.train_step()
+                torch.cuda.synchronize()
+                assert torch.equal(hnn._w16(s.encoder.resnet[7][2].conv3, torch.float16), sh)
+            del tr, s, t, p
+    finally:
+        ops.gemm_raw = orig
+        hnn._TRUNK16[0] = prev
+        hnn.clear_weight_shadows()
+    for k in ("total_loss", "token_kd_loss", "feature_kd_loss"):
+        assert abs(losses[True][k] - losses[False][k]) <= 1e-2 * max(abs(losses[False][k]), 1e-3), (k, losses)

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Weight-gradient convolutions of layer3 / layer4 on native fp16 operands: time per (tile, split-K) (GPU box)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imagecaptioner_amd import ops  # noqa: E402
+
+
+def timeit(f, iters=20):
+    f(); f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        f()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+B = 64
+dt = torch.float16
+for (H, Cin, Cout, R) in [(14, 256, 256, 3), (14, 256, 1024, 1), (14, 1024, 256, 1), (7, 512, 512, 3), (7, 512, 2048, 1), (7, 2048, 512, 1)]:
+    pad = R // 2
+    x = ops.cast16(torch.randn(B, H, H, Cin, device="cuda"), dt)
+    dy = ops.cast16(torch.randn(B, H, H, Cout, device="cuda"), dt)
+    dw = torch.zeros(Cout, R, R, Cin, device="cuda")
+    K, N = B * H * H, R * R * Cin
+    conv = (B, H, H, Cin, H, H, Cout, R, R, 1, pad)
+    fl = 2.0 * Cout * N * K
+    print(f"wgrad Cout {Cout} N {N} K {K}  ({fl / 1e9:.1f} GF)")
+    for tile in (1, 2, 3, 4):
+        line = []
+        for sk in (1, 2, 4, 8, 16, 24, 48):
+            kw = dict(splitk=sk) if sk > 1 else dict(accumulate=True)
+            t = timeit(lambda: ops.gemm_raw(ops.OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, conv=conv, tile=tile, h16=dt, **kw))
+            line.append(f"sk{sk:2d} {t:6.1f}us {fl / t / 1e6:4.0f}TF")
+        print(f"  tile {tile}: " + "  ".join(line))
