@@ -274,78 +274,122 @@ __global__ void bn_train_apply_kernel(const T* __restrict__ x, const double* __r
 // thread, fp64 LDS combine, fp64 atomics; invstd is applied once to the finished dot product.  (Both sums are
 // differences of large terms behind a mean-subtracting layer; the kernel is HBM-bound, the fp64 VALU work is free.)
 struct d4 { double x, y, z, w; };
-template <typename T>
-__global__ void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+// G float4 groups per thread = one 16-byte load of every tensor: G = 1 for fp32 storage, 2 (8 channels) for 16-bit storage —
+// with 8-byte loads the 16-bit form was latency-bound at 1.9 TB/s (42 us against the fp32 form's 28 on 12544 x 1024).
+template <typename T, int G>
+__device__ __forceinline__ void ldg16(const T* p, long o, float4 (&out)[G]) {     // o in units of 4 * G elements
+  if constexpr (G == 1) out[0] = ld4(p, o);
+  else {
+    typedef T h8 __attribute__((ext_vector_type(8)));
+    typedef float f8 __attribute__((ext_vector_type(8)));
+    const f8 f = __builtin_convertvector(reinterpret_cast<const h8*>(p)[o], f8);
+    out[0] = make_float4(f[0], f[1], f[2], f[3]);
+    out[1] = make_float4(f[4], f[5], f[6], f[7]);
+  }
+}
+__device__ __forceinline__ void bn_red_acc(d4& dg, d4& dx, float4 g, const float4 yy, bool masked, float hi, const float4 xv, const d4& mu) {
+  if (masked) {
+    g.x = (yy.x > 0.f && yy.x < hi) ? g.x : 0.f; g.y = (yy.y > 0.f && yy.y < hi) ? g.y : 0.f;
+    g.z = (yy.z > 0.f && yy.z < hi) ? g.z : 0.f; g.w = (yy.w > 0.f && yy.w < hi) ? g.w : 0.f;
+  }
+  dg.x += g.x; dg.y += g.y; dg.z += g.z; dg.w += g.w;
+  dx.x = fma((double)g.x, (double)xv.x - mu.x, dx.x); dx.y = fma((double)g.y, (double)xv.y - mu.y, dx.y);
+  dx.z = fma((double)g.z, (double)xv.z - mu.z, dx.z); dx.w = fma((double)g.w, (double)xv.w - mu.w, dx.w);
+}
+template <typename T, int U>
+__global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                      const T* __restrict__ x, const float* __restrict__ mean,
                                      const float* __restrict__ inv, double* __restrict__ sum_g,
                                      double* __restrict__ sum_gx, int copies, long stride, long M, int C, float hi) {
-  const int C4 = C >> 2;
-  const int lanes = C4 < NT ? C4 : NT;     // threads along channels
-  const int rows = NT / lanes;             // threads along rows (threads beyond rows * lanes idle: C/4 need not divide 256)
+  constexpr int G = sizeof(T) == 2 ? 2 : 1;
+  const int CG = C / (4 * G);              // 16-byte channel groups per row (launcher: C % (4 G) == 0)
+  const int lanes = CG < NT ? CG : NT;     // threads along channels
+  const int rows = NT / lanes;             // threads along rows (threads beyond rows * lanes idle: CG need not divide 256)
   const int tc = threadIdx.x % lanes, tr = threadIdx.x / lanes;
-  __shared__ d4 sh_g[NT], sh_x[NT];
-  for (int cbase = blockIdx.x * lanes; cbase < C4; cbase += gridDim.x * lanes) {     // block-uniform trip count (barriers inside)
-    const int c4 = cbase + tc;
-    const bool cok = c4 < C4;
-    const float4 muf = cok ? reinterpret_cast<const float4*>(mean)[c4] : make_float4(0, 0, 0, 0);
-    const d4 mu = {muf.x, muf.y, muf.z, muf.w};
-    d4 dg = {0, 0, 0, 0}, dx = {0, 0, 0, 0};
+  __shared__ d4 sh[2][G][NT];               // partial sums of the row-threads; reused as the block's final [2][lanes * 4 G] doubles
+  auto& sh_g = sh[0]; auto& sh_x = sh[1];
+  for (int cbase = blockIdx.x * lanes; cbase < CG; cbase += gridDim.x * lanes) {     // block-uniform trip count (barriers inside)
+    const int cg = cbase + tc;
+    const bool cok = cg < CG;
+    d4 mu[G], dg[G], dx[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+      const float4 muf = cok ? reinterpret_cast<const float4*>(mean)[cg * G + k] : make_float4(0, 0, 0, 0);
+      mu[k] = d4{muf.x, muf.y, muf.z, muf.w};
+      dg[k] = d4{0, 0, 0, 0}; dx[k] = d4{0, 0, 0, 0};
+    }
     if (tr < rows && cok) {
-      // 4 rows per trip: 12 independent 16-byte loads in flight per thread (one row per trip left the kernel
+      // U rows per trip: 3 U independent 16-byte loads in flight per thread (one row per trip left the kernel
       // latency-bound at ~3.6 TB/s with 1.5 workgroups per CU)
-      // (16-bit storage: 8 rows per trip keep the same number of bytes in flight)
-      constexpr int U = sizeof(T) == 2 ? 8 : 4;
       const long step = (long)gridDim.y * rows;
       long m = blockIdx.y * (long)rows + tr;
       for (; m + (U - 1) * step < M; m += U * step) {
-        float4 g[U], xv[U], yy[U];
+        float4 g[U][G], xv[U][G], yy[U][G];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const long o = (m + u * step) * C4 + c4;
-          g[u] = ld4(dy, o);
-          xv[u] = ld4(x, o);
-          if (y) yy[u] = ld4(y, o);
+          const long o = (m + u * step) * CG + cg;
+          ldg16<T, G>(dy, o, g[u]);
+          ldg16<T, G>(x, o, xv[u]);
+          if (y) ldg16<T, G>(y, o, yy[u]);
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-          if (y) {
-            g[u].x = (yy[u].x > 0.f && yy[u].x < hi) ? g[u].x : 0.f; g[u].y = (yy[u].y > 0.f && yy[u].y < hi) ? g[u].y : 0.f;
-            g[u].z = (yy[u].z > 0.f && yy[u].z < hi) ? g[u].z : 0.f; g[u].w = (yy[u].w > 0.f && yy[u].w < hi) ? g[u].w : 0.f;
-          }
-          dg.x += g[u].x; dg.y += g[u].y; dg.z += g[u].z; dg.w += g[u].w;
-          dx.x = fma((double)g[u].x, (double)xv[u].x - mu.x, dx.x); dx.y = fma((double)g[u].y, (double)xv[u].y - mu.y, dx.y);
-          dx.z = fma((double)g[u].z, (double)xv[u].z - mu.z, dx.z); dx.w = fma((double)g[u].w, (double)xv[u].w - mu.w, dx.w);
-        }
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int k = 0; k < G; ++k) bn_red_acc(dg[k], dx[k], g[u][k], yy[u][k], y != nullptr, hi, xv[u][k], mu[k]);
       }
       for (; m < M; m += step) {
-        const long o = m * C4 + c4;
-        float4 g = ld4(dy, o);
-        if (y) {
-          const float4 yy = ld4(y, o);
-          g.x = (yy.x > 0.f && yy.x < hi) ? g.x : 0.f; g.y = (yy.y > 0.f && yy.y < hi) ? g.y : 0.f;
-          g.z = (yy.z > 0.f && yy.z < hi) ? g.z : 0.f; g.w = (yy.w > 0.f && yy.w < hi) ? g.w : 0.f;
-        }
-        const float4 xv = ld4(x, o);
-        dg.x += g.x; dg.y += g.y; dg.z += g.z; dg.w += g.w;
-        dx.x = fma((double)g.x, (double)xv.x - mu.x, dx.x); dx.y = fma((double)g.y, (double)xv.y - mu.y, dx.y);
-        dx.z = fma((double)g.z, (double)xv.z - mu.z, dx.z); dx.w = fma((double)g.w, (double)xv.w - mu.w, dx.w);
+        const long o = m * CG + cg;
+        float4 g[G], xv[G], yy[G];
+        ldg16<T, G>(dy, o, g);
+        ldg16<T, G>(x, o, xv);
+        if (y) ldg16<T, G>(y, o, yy);
+#pragma unroll
+        for (int k = 0; k < G; ++k) bn_red_acc(dg[k], dx[k], g[k], yy[k], y != nullptr, hi, xv[k], mu[k]);
       }
     }
-    sh_g[threadIdx.x] = dg; sh_x[threadIdx.x] = dx;
+#pragma unroll
+    for (int k = 0; k < G; ++k) { sh_g[k][threadIdx.x] = dg[k]; sh_x[k][threadIdx.x] = dx[k]; }
     __syncthreads();
+    // combine the row-threads in LDS, then add the block's 2 x (lanes * 4 G) channel sums with CONSECUTIVE channels on
+    // consecutive lanes: one wave-instruction = 64 doubles = 4 cache lines.  (Adding straight from the owning threads
+    // strides the lanes by 32 / 64 bytes: 16 / 32 lines per instruction, and the L2 prices atomics per line touched —
+    // measured on 3136 x 2048: 144 / 76 / 44 / 33 us with 800 / 400 / 200 / 100 row-blocks, i.e. the tail was the kernel.)
+    double* fin = reinterpret_cast<double*>(&sh[0][0][0]);         // [2][lanes * 4 G] <= 2 * G * NT * 4 doubles, once the partials are consumed
+    d4 tg[G], tx[G];
     if (tr == 0 && cok) {
-      for (int r = 1; r < rows; ++r) {
-        const d4 a = sh_g[r * lanes + tc], b = sh_x[r * lanes + tc];
-        dg.x += a.x; dg.y += a.y; dg.z += a.z; dg.w += a.w;
-        dx.x += b.x; dx.y += b.y; dx.z += b.z; dx.w += b.w;
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        tg[k] = dg[k]; tx[k] = dx[k];
+        for (int r = 1; r < rows; ++r) {
+          const d4 a = sh_g[k][r * lanes + tc], b = sh_x[k][r * lanes + tc];
+          tg[k].x += a.x; tg[k].y += a.y; tg[k].z += a.z; tg[k].w += a.w;
+          tx[k].x += b.x; tx[k].y += b.y; tx[k].z += b.z; tx[k].w += b.w;
+        }
+        const float4 iv = reinterpret_cast<const float4*>(inv)[cg * G + k];
+        tx[k].x *= iv.x; tx[k].y *= iv.y; tx[k].z *= iv.z; tx[k].w *= iv.w;
       }
-      const float4 iv = reinterpret_cast<const float4*>(inv)[c4];
+    }
+    __syncthreads();                                               // every partial has been read
+    const int nch = lanes * 4 * G;                                 // channels of this block's column range
+    if (tr == 0) {
+#pragma unroll
+      for (int k = 0; k < G; ++k) {
+        double* fg = fin + (tc * G + k) * 4; double* fx = fin + nch + (tc * G + k) * 4;
+        const bool ok = cok;
+        fg[0] = ok ? tg[k].x : 0.0; fg[1] = ok ? tg[k].y : 0.0; fg[2] = ok ? tg[k].z : 0.0; fg[3] = ok ? tg[k].w : 0.0;
+        fx[0] = ok ? tx[k].x : 0.0; fx[1] = ok ? tx[k].y : 0.0; fx[2] = ok ? tx[k].z : 0.0; fx[3] = ok ? tx[k].w : 0.0;
+      }
+    }
+    __syncthreads();
+    {
       // up to 1024 row-blocks add into the same 2 x C addresses: spread them over `copies` accumulator rows (the apply
-      // pass folds them) — same-address fp64 atomics serialise in L2 and were most of this kernel's time
+      // pass folds them) — same-address fp64 atomics serialise in L2
       const long co = (long)(blockIdx.y % copies) * stride;
-      double* sg = sum_g + co + c4 * 4; double* sx = sum_gx + co + c4 * 4;
-      atomicAdd(sg + 0, dg.x); atomicAdd(sg + 1, dg.y); atomicAdd(sg + 2, dg.z); atomicAdd(sg + 3, dg.w);
-      atomicAdd(sx + 0, dx.x * iv.x); atomicAdd(sx + 1, dx.y * iv.y); atomicAdd(sx + 2, dx.z * iv.z); atomicAdd(sx + 3, dx.w * iv.w);
+      const int c0 = cbase * 4 * G;
+      for (int i = threadIdx.x; i < 2 * nch; i += NT) {
+        const int which = i >= nch, cl = i - which * nch;
+        if (c0 + cl < C) atomicAdd((which ? sum_gx : sum_g) + co + c0 + cl, fin[i]);
+      }
     }
     __syncthreads();
   }
@@ -737,7 +781,9 @@ int bn_bwd_reduce_impl(const T* dy, const T* y, const T* x, const float* mean, c
                       double* sum_g, double* sum_gx, int copies, int64_t stride, long M, int C, int act, void* stream) {
   ICK_REQUIRE(copies >= 1 && (copies == 1 || stride >= C), "ick_bn_bwd_reduce: copies >= 1, stride >= C");
   ICK_REQUIRE(dy && x && mean && invstd && sum_g && sum_gx && C % 4 == 0 && M > 0, "ick_bn_bwd_reduce: bad arguments");
-  const int C4 = C / 4;
+  constexpr int G = sizeof(T) == 2 ? 2 : 1;              // 16-byte channel groups (see the kernel)
+  ICK_REQUIRE(C % (4 * G) == 0, "ick_bn_bwd_reduce: C must be a multiple of %d", 4 * G);
+  const int C4 = C / (4 * G);
   const int lanes = C4 < NT ? C4 : NT;
   const int rows = NT / lanes;
   const int gx = (C4 + lanes - 1) / lanes;
@@ -749,8 +795,11 @@ int bn_bwd_reduce_impl(const T* dy, const T* y, const T* x, const float* mean, c
   const long gmax = (M + rows * 4 - 1) / (rows * 4);          // at least one 4-row trip per thread
   if (gy > gmax) gy = gmax;
   if (gy < 1) gy = 1;
-  ICK_LAUNCH(bn_bwd_reduce_kernel<T>, dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, copies, (long)stride, M, C,
-             act == 2 ? 6.f : INFINITY);
+  static const int u8 = [] { const char* e = getenv("ICK_BN_BWD_U"); return e && atoi(e) == 8; }();   // A/B runs
+  if (u8) ICK_LAUNCH((bn_bwd_reduce_kernel<T, 8>), dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, copies, (long)stride, M, C,
+                     act == 2 ? 6.f : INFINITY);
+  else ICK_LAUNCH((bn_bwd_reduce_kernel<T, 4>), dim3(gx, (int)gy), dim3(NT), 0, ST, dy, y, x, mean, invstd, sum_g, sum_gx, copies, (long)stride, M, C,
+                  act == 2 ? 6.f : INFINITY);
   return ick::launch_status("bn_bwd_reduce");
 }
 
