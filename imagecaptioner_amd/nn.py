@@ -397,6 +397,27 @@ def bottleneck_forward(blk: Bottleneck, x, train: bool, arena=None, counters=Non
                      idv=idv)
 
 
+# ---- weight gradients on a side stream.  In the trunk's backward the weight gradient of a convolution is needed only by the
+# optimizer, the data gradient by the very next kernel: with a side stream installed (KDTrainer does), every conv_wgrad is
+# launched there — a parallel branch of the captured graph — meant to fill the ramp-up / tail / epilogue bubbles of the
+# data-gradient and BatchNorm kernels on the main stream (each launch has ~17 us of such fixed cost, profiles/r02*).
+# trunk_backward_stage joins the branch before it returns (the gradient buckets leave after that).  Measured: not a win on
+# this step (fp32 28.19 vs 27.58 ms, fp16 17.59 vs 17.71 ms) -> an opt-in of KDTrainer (ICK_WGRAD_STREAM=1), off by default.
+_WGRAD_SIDE = {"stream": None, "keep": []}
+
+
+def set_wgrad_stream(stream) -> None:
+    """stream: a torch.cuda.Stream, or None to run weight gradients in program order on the current stream."""
+    _WGRAD_SIDE["stream"], _WGRAD_SIDE["keep"] = stream, []
+
+
+def _join_wgrad_stream() -> None:
+    side = _WGRAD_SIDE["stream"]
+    if side is not None and _WGRAD_SIDE["keep"]:
+        torch.cuda.current_stream().wait_stream(side)
+        _WGRAD_SIDE["keep"] = []          # the operands were kept alive until here: the allocator must not hand them out early
+
+
 def bottleneck_backward(blk: Bottleneck, r: dict, d, need_in: bool, sums_arena=None):
     """Backward of bottleneck_forward (train-mode BatchNorm): d = dL/d out; accumulates every weight / BatchNorm gradient
     into .grad and returns dL/dx (None unless need_in)."""
@@ -407,8 +428,16 @@ def bottleneck_backward(blk: Bottleneck, r: dict, d, need_in: bool, sums_arena=N
                           sums=sums_arena.take(2 * ops.BN_BWD_COPIES, C).view(2, ops.BN_BWD_COPIES, C) if sums_arena is not None else None)
 
     def wgrad(conv, dyv, xin):
-        if conv.weight.requires_grad:
+        if not conv.weight.requires_grad:
+            return
+        side = _WGRAD_SIDE["stream"]
+        if side is None:
             ops.conv_wgrad(dyv, xin, conv.packed_grad(), conv.stride, conv.padding)
+            return
+        side.wait_stream(torch.cuda.current_stream())      # dyv is ready
+        with torch.cuda.stream(side):
+            ops.conv_wgrad(dyv, xin, conv.packed_grad(), conv.stride, conv.padding)
+        _WGRAD_SIDE["keep"].append((dyv, xin))
 
     dx3, g3 = bnb(d, r["out"], r["r3"], r["m3"], r["i3"], blk.bn3, want_g=True)
     wgrad(blk.conv3, dx3, r["a2"])
@@ -521,6 +550,7 @@ def trunk_backward_stage(state: dict, stop: int) -> None:
     for i in range(state["next"], stop - 1, -1):
         state["d"] = bottleneck_backward(blocks[i], recs[i - first], state["d"], i > first or stem is not None, state["sums"])
         recs[i - first] = None                                       # free this block's activations
+    _join_wgrad_stream()
     state["next"] = stop - 1
     if stem is not None and state["next"] < first:                   # CNNEncoder(fine_tune=False): max-pool, bn1, conv1 adjoints
         bn, conv = stem["bn"], stem["conv"]

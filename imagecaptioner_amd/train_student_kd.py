@@ -19,6 +19,7 @@ Design (MI355X-first):
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -176,6 +177,10 @@ class KDTrainer:
         if len(self.buckets) != 3:
             self.bucketed = False
         self.comm_stream = torch.cuda.Stream() if (self.bucketed and self.device.type == "cuda") else None
+        # ICK_WGRAD_STREAM=1: weight gradients of the trunk on their own stream / graph branch (hnn.set_wgrad_stream).  Off by
+        # default — measured: the fp32 step gets SLOWER (28.19 vs 27.58 ms: two matrix-pipe-bound GEMMs share the LDS and L2 of
+        # every CU), the fp16 step gains 0.7 % (17.59 vs 17.71 ms), inside the box-to-box noise.
+        self.wgrad_stream = torch.cuda.Stream() if (cuda and os.environ.get("ICK_WGRAD_STREAM", "0") == "1") else None
         # 16-bit training regime (hnn._TRUNK16): the trunk reads bf16 / fp16 weights.  One cast of the encoder segment of the
         # flat parameter buffer per step keeps a flat 16-bit shadow current; every trainable conv weight gets a view of it.
         self.flat16 = None
@@ -194,6 +199,7 @@ class KDTrainer:
     # ------------------------------------------------------------------ the step body
     def _stage(self, k: int):
         """stage k of the staged (data-parallel) step; see __init__."""
+        hnn.set_wgrad_stream(self.wgrad_stream)
         if k == 0:
             with hnn.deferred_trunk_backward() as box:
                 out = self._forward_backward()
@@ -208,6 +214,7 @@ class KDTrainer:
                 hnn.trunk_backward_stage(self._trunk_state, self._l4_first if k == 1 else 0)
             if k == 2:
                 self._trunk_state = None
+        hnn.set_wgrad_stream(None)
 
     def _reduce_bucket(self, k: int, boundary: bool):
         """all-reduce(SUM) of bucket k on the communication stream, behind everything the launch stream has enqueued so far."""
@@ -251,10 +258,14 @@ class KDTrainer:
             s_out = {"logits": logits, "encoder_features": enc, "hidden_states": hids}
             t_out["encoder_features"] = self.projectors["encoder"](t_out["encoder_features"])
             out5 = self.loss.forward_device(s_out, t_out, ctg)
-            if self.scaler is None:
-                out5[0].backward()
-            else:
-                out5[0].backward(self.scaler[0])          # scaler.scale(loss).backward()
+            hnn.set_wgrad_stream(self.wgrad_stream)
+            try:
+                if self.scaler is None:
+                    out5[0].backward()
+                else:
+                    out5[0].backward(self.scaler[0])          # scaler.scale(loss).backward()
+            finally:
+                hnn.set_wgrad_stream(None)
         self.out5 = out5
         return out5
 
