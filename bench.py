@@ -321,8 +321,8 @@ def main():
         achieved = gflop_img * args.batch / step_ms_dev                   # GFLOP / ms = TFLOP/s, this rank's GPU
         traffic, traffic_src = measured_traffic(args.batch)
         peak = mfma_peak(args.precision, gflop_img - GFLOP_TEACHER)
-        dtype = {"f32": "f32", "bf16": "bf16 student (fp32 accumulate, fp32 master weights) + f32 teacher",
-                 "fp16": "fp16 student (fp32 accumulate, fp32 master weights, device GradScaler) + f32 teacher",
+        dtype = {"f32": "f32", "bf16": "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher",
+                 "fp16": "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler) + f32 teacher",
                  "bf16x3": "split-bf16x3 student + f32 teacher"}[args.precision]
         out = {
             "metric": "images/sec KD train step (teacher+student fwd + KD loss + bwd)", "value": round(ips, 2),
@@ -348,8 +348,8 @@ def main():
             if args.precision == "f32":
                 # the reference's AMP regime (train_student_kd.py:239,271: fp16 autocast + GradScaler), then its bf16 twin
                 out["mixed_precision"] = {}
-                for prec2, label in (("fp16", "fp16 student (fp32 accumulate, fp32 master weights, device GradScaler 2^16) + f32 teacher"),
-                                     ("bf16", "bf16 student (fp32 accumulate, fp32 master weights) + f32 teacher")):
+                for prec2, label in (("fp16", "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler 2^16) + f32 teacher"),
+                                     ("bf16", "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher")):
                     ips2, dt2, dev2, loss2 = run_kd(args, prec2, dev, rank, world, log)
                     ach2 = GFLOP_PER_IMAGE * args.batch / (dev2 / args.steps)
                     out["mixed_precision"][prec2] = {"dtype": label, "value": round(ips2, 2), "unit": "images/s",

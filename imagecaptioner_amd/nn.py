@@ -299,14 +299,14 @@ def _w16(conv: Conv2d, dt: torch.dtype) -> torch.Tensor:
     if sh is not None and sh[0]() is conv.weight and sh[1].dtype == dt:
         return sh[1]
     w = conv.packed()
-    if not conv.weight.requires_grad:       # frozen: changes only through torch (load_state_dict) -> version counter
-        key = (w.data_ptr(), conv.weight._version, dt)
-        cached = getattr(conv, "_ick_w16", None)
-        if cached is None or cached[0] != key:
-            cached = (key, ops.cast16(w.contiguous(), dt))
-            conv._ick_w16 = cached
-        return cached[1]
-    return ops.cast16(w.contiguous(), dt)
+    # cached copy: a frozen weight changes only through torch (load_state_dict -> version counter); a trainable one also by
+    # raw pointer (the flat AdamW pass), which bump_param_generation announces (inference between training steps)
+    key = (w.data_ptr(), conv.weight._version, dt, _PARAM_GENERATION[0] if conv.weight.requires_grad else -1)
+    cached = getattr(conv, "_ick_w16", None)
+    if cached is None or cached[0] != key:
+        cached = (key, ops.cast16(w.contiguous(), dt))
+        conv._ick_w16 = cached
+    return cached[1]
 
 
 def _wlike(conv: Conv2d, like: torch.Tensor) -> torch.Tensor:
@@ -339,7 +339,8 @@ def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool,
     co = _eval_coeffs(bn)
     cin, cout = w.shape[3], w.shape[0]
     if (cin % 32 == 0 or cin == 4) and cout % 4 == 0:       # shapes the LDS-DMA kernels take (every ResNet-50 conv)
-        y = ops.conv_fwd(x, w, conv.stride, conv.padding, scale=co[0], shift=co[1], residual=residual, relu=relu)
+        y = ops.conv_fwd(x, w, conv.stride, conv.padding, scale=co[0], shift=co[1], residual=residual, relu=relu,
+                         out_dtype=out_dtype)
     else:                                                   # two passes: conv, then the affine map + residual + ReLU
         y = ops.scale_shift_act(ops.conv_fwd(x, w, conv.stride, conv.padding), co[0], co[1], residual, relu)
     return y, None, None, None
@@ -483,9 +484,10 @@ class ResNetTrunkFn(Function):
         if train:
             # up to 8 accumulator copies per BatchNorm (ops.stat_copies)
             arena, counters = _Arena(2 * (64 + _bn_channels(blocks)) * 8, torch.float64, images.device), []
-        # 16-bit activation storage (see _TRUNK16): train mode under a 16-bit GEMM precision, frozen stem, channel counts
-        # the 16-bit kernels take (every ResNet-50 layer)
-        dt16 = _H16_OF.get(ops.gemm_precision()) if (train and _TRUNK16[0] and not stem_trainable) else None
+        # 16-bit activation storage (see _TRUNK16) under a 16-bit GEMM precision: train mode with a frozen stem (its adjoint
+        # kernels are fp32), and eval mode (cfg2's bf16 inference: conv + folded BatchNorm + residual + ReLU in one epilogue,
+        # 16-bit in, 16-bit out)
+        dt16 = _H16_OF.get(ops.gemm_precision()) if (_TRUNK16[0] and (not train or not stem_trainable)) else None
         ctx.dt16 = dt16
         ys, raw_s, mean_s, inv_s = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters,
                                            out_dtype=dt16)

@@ -363,9 +363,12 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Opt
     K = R * S * Cin
     if h16 is not None or y.dtype != _F32:
         # (fp32 operands + 16-bit y: the 4-channel stem under ops.precision("bf16" / "fp16") — ick_gemm_bf16 with io16)
-        assert scale is None, "the eval-mode fused form runs on fp32 storage"
+        fused = scale is not None      # eval mode: y = relu(scale * conv + shift + residual) in the epilogue, as on fp32 storage
+        assert not (fused and stats is not None)
         gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout,
-                 residual=_ptr(residual), ldr=Cout, act=ACT_RELU if relu else ACT_NONE,
+                 residual=_ptr(residual), ldr=Cout,
+                 act=((ACT_RELU if relu else ACT_NONE) | _lib.ACT_POST_RESIDUAL) if fused else (ACT_RELU if relu else ACT_NONE),
+                 bias=shift.data_ptr() if fused else None, col_scale=scale.data_ptr() if fused else None,
                  stat_sum=_ptr(stats[0]) if stats is not None else None, stat_sq=_ptr(stats[1]) if stats is not None else None,
                  stat_copies=stats[0].shape[0] if (stats is not None and stats[0].dim() == 2) else 1, stat_stride=Cout,
                  conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), h16=h16,
