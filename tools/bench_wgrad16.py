@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Weight-gradient convolutions of layer3 / layer4 on native fp16 operands: time per (tile, split-K) (GPU box)."""
+"""Weight-gradient convolutions of layer3 / layer4 on native fp16 operands (or fp32: argument f32): time per (tile, split-K)
+(GPU box)."""
 import os
 import sys
 
@@ -22,17 +23,19 @@ def timeit(f, iters=20):
 
 
 B = 64
-dt = torch.float16
+dt = None if (len(sys.argv) > 1 and sys.argv[1] == "f32") else torch.float16
 for (H, Cin, Cout, R) in [(14, 256, 256, 3), (14, 256, 1024, 1), (14, 1024, 256, 1), (7, 512, 512, 3), (7, 512, 2048, 1), (7, 2048, 512, 1)]:
     pad = R // 2
-    x = ops.cast16(torch.randn(B, H, H, Cin, device="cuda"), dt)
-    dy = ops.cast16(torch.randn(B, H, H, Cout, device="cuda"), dt)
+    x = torch.randn(B, H, H, Cin, device="cuda")
+    dy = torch.randn(B, H, H, Cout, device="cuda")
+    if dt is not None:
+        x, dy = ops.cast16(x, dt), ops.cast16(dy, dt)
     dw = torch.zeros(Cout, R, R, Cin, device="cuda")
     K, N = B * H * H, R * R * Cin
     conv = (B, H, H, Cin, H, H, Cout, R, R, 1, pad)
     fl = 2.0 * Cout * N * K
     print(f"wgrad Cout {Cout} N {N} K {K}  ({fl / 1e9:.1f} GF)")
-    for tile in (1, 2, 3, 4):
+    for tile in ((1, 2, 3, 4) if dt is not None else (3, 19, 67, 83, 259)):
         line = []
         for sk in (1, 2, 4, 8, 16, 24, 48):
             kw = dict(splitk=sk) if sk > 1 else dict(accumulate=True)
