@@ -77,8 +77,11 @@ __device__ __forceinline__ void glds16(const float* src, unsigned lds_wave_base)
 
 // NW = waves per workgroup: 4 (2 x 2 wave grid) or 8 (4 x 2, BM = 128 only: twice the waves per SIMD behind the same LDS
 // footprint — the 128-row tiles otherwise leave 2-3 waves per SIMD to cover the per-k-tile barrier and the epilogues)
+// (tiles above 128 x 128 — the 256 x 256 tile of the native 16-bit variants — hold their two buffers in 128 KB of DYNAMIC LDS,
+//  one workgroup per CU, and keep their 128 accumulator registers per lane with the full 256-VGPR budget)
+extern __shared__ __attribute__((aligned(16))) float glds_dyn_lds[];
 template <int OP, int BM, int BN, int NBUF, int TERMS, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
+__global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_glds_kernel(const P p) {
   constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
   constexpr int NT = NW * 64;
   constexpr int WM = BM / (NW / 2), WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -89,7 +92,9 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
   constexpr int A_RPI = 64 / A_TPK, B_RPI = 64 / B_TPK;  // k-rows per DMA instruction (x-contiguous)
   constexpr bool H16OUT = TERMS != 0 && TERMS != 3;       // variants that can write C / read the residual as 16-bit (P.c16 / P.r16)
 
-  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF];
+  constexpr bool DYN = NBUF * BUF * 4 > 65536;          // beyond the static LDS limit: the launcher passes the size
+  __shared__ __attribute__((aligned(16))) float lds_static[DYN ? 4 : NBUF * BUF];
+  float* const lds = DYN ? glds_dyn_lds : lds_static;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -177,7 +182,8 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
     }
   }
 
-  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
+  const unsigned lds_base = DYN ? (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)glds_dyn_lds
+                                : (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds_static;
   // issue the LDS-DMA of k-tile kt into buffer buf
   auto issue = [&](int kt, int buf) {
     const int k0 = kbeg + kt * BK;
@@ -366,15 +372,19 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
     cb = cb + 1 == NBUF ? 0 : cb + 1;
     const float* Bb = Ab + A_SZ;
     if constexpr (TERMS == 0 || TERMS >= 5) {
-      float4 av[2][TM], bv[2][TN];
+      // fragment registers: two sets (the next group's reads fly under this group's MFMAs); ONE set for the 256 x 256 tile,
+      // whose 128 accumulator registers leave no room for a second (spills otherwise) — its two waves per SIMD cover each
+      // other's LDS latency instead, and its reads for group j + 1 are issued behind group j's eight MFMAs
+      constexpr int FB = BM * BN > 128 * 128 ? 1 : 2;
+      float4 av[FB][TM], bv[FB][TN];
   #pragma unroll
       for (int i = 0; i < TM; ++i) av[0][i] = frag_a(Ab, 0, i);
   #pragma unroll
       for (int t = 0; t < TN; ++t) bv[0][t] = frag_b(Bb, 0, t);
   #pragma unroll
       for (int j = 0; j < BK / 8; ++j) {
-        const int cur = j & 1, nxt = cur ^ 1;
-        if (j + 1 < BK / 8) {
+        const int cur = FB == 2 ? (j & 1) : 0, nxt = FB == 2 ? (cur ^ 1) : 0;
+        if (FB == 2 && j + 1 < BK / 8) {
   #pragma unroll
           for (int i = 0; i < TM; ++i) av[nxt][i] = frag_a(Ab, j + 1, i);
   #pragma unroll
@@ -398,6 +408,12 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
             acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].w, bv[cur][t].w, acc[i][t], 0, 0, 0);
           }
         __builtin_amdgcn_sched_barrier(0);
+        if (FB == 1 && j + 1 < BK / 8) {
+  #pragma unroll
+          for (int i = 0; i < TM; ++i) av[0][i] = frag_a(Ab, j + 1, i);
+  #pragma unroll
+          for (int t = 0; t < TN; ++t) bv[0][t] = frag_b(Bb, j + 1, t);
+        }
       }
     } else {
       f32x8 av[2][TM], bv[2][TN];
@@ -438,7 +454,8 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
           }
       }
     }
-    if (TERMS == 0 && ++chain == p.chunk_tiles && kt + 1 < nkt) {   // (16-bit products: operand rounding dominates the chain's)
+    if constexpr (TERMS == 0)          // (16-bit products: operand rounding dominates the chain's — and `acc + 0.0f` is not
+    if (++chain == p.chunk_tiles && kt + 1 < nkt) {   //  foldable, so an unconditional master sum would cost 16 TM TN live registers)
       chain = 0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -450,10 +467,12 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
         }
     }
   }
+  if constexpr (TERMS == 0) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t];
+      for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t];
+  }
 
   // ---------------------------------------------------------------- epilogue
   // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -470,8 +489,16 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
     // way) and leaves as 16-byte stores along n, 2 x 512-byte rows (128-wide tiles) per wave-instruction instead of
     // 2 x 128 bytes: the direct path below issues 4x the store instructions and prices 5-30 % of a short-K GEMM
     // (profiles/r01g_ablation_glds.log, V1 -> V2).  The residual is read in the same coalesced pattern.
-    __syncthreads();                       // every wave is out of the k-loop: the LDS buffers become the C tile [BM][BN]
+    // A tile larger than the buffers (256 x 256: 256 KB of fp32 against 128 KB of LDS) leaves in SLABS row slabs.
+    constexpr int SLABS = (BM * BN + NBUF * BUF - 1) / (NBUF * BUF);
+    constexpr int SROWS = BM / SLABS;
+    static_assert(BM % SLABS == 0 && SROWS % WM == 0, "a wave's rows lie in one slab");
     float* ct = lds;
+#pragma unroll
+    for (int sl = 0; sl < SLABS; ++sl) {
+    const int srow0 = sl * SROWS;
+    __syncthreads();                       // every wave is out of the k-loop / the previous slab is stored: the LDS buffers become the C slab [SROWS][BN]
+    if (SLABS == 1 || (wm * WM) / SROWS == sl) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nl = wn * WN + j * 32 + (lane & 31);
@@ -489,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
           const float v = acc[i][j][r] * alpha;
           if (nok && m0 + row < p.M) { ssum += v; ssq = fmaf(v, v, ssq); }
           const float u = fmaf(v, csc, bias);
-          ct[row * BN + nl] = post ? u : act_fn(u, act);
+          ct[(row - srow0) * BN + nl] = post ? u : act_fn(u, act);
         }
       }
       if (p.stat_sum) {
@@ -501,10 +528,11 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
         }
       }
     }
+    }
     __syncthreads();
     constexpr int C4 = BN / 4;
-    for (int c = tid; c < BM * C4; c += NT) {
-      const int row = c / C4, col = (c - row * C4) * 4;
+    for (int c = tid; c < SROWS * C4; c += NT) {
+      const int row = srow0 + c / C4, col = (c % C4) * 4;
       const int m = m0 + row, n = n0 + col;
       if (m < p.M && n < p.N) {            // N % 4 == 0 on this path: the whole chunk is in range
         long mr = m;
@@ -512,7 +540,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
           const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
           mr = ((long)b * p.H + 2 * (q / w2) + py) * p.W + 2 * (q % w2) + px;
         }
-        float4 v = *reinterpret_cast<const float4*>(ct + row * BN + col);
+        float4 v = *reinterpret_cast<const float4*>(ct + (row - srow0) * BN + col);
         using h4 = typename Half16<TERMS>::x4;
         if (Rg) {
           float4 q;
@@ -531,6 +559,7 @@ __global__ __launch_bounds__(NW * 64, 2) void igemm_glds_kernel(const P p) {
         if (mode == 1) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *dst = v;
       }
+    }
     }
     return;
   }
@@ -600,7 +629,16 @@ int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) 
   if ((p.c16 || p.r16) && !((TERMS != 0 && TERMS != 3) && p.ep_vec && p.splitk == 1))
     return ick::fail(-1, "igemm: a 16-bit C / residual needs a 16-bit MFMA variant of the LDS-DMA kernel, N %% 4, ldc %% 4, ldr %% 4 and no split-K");
   dim3 grid(p.tiles_n * ((p.M - m_begin + BM - 1) / BM), 1, nz);
-  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>), grid, dim3(NW * 64), 0, st, p);
+  constexpr size_t lds_bytes = (size_t)NBUF * (BM + BN) * BK * 4;
+  size_t dyn = 0;
+  if constexpr (lds_bytes > 65536) {       // dynamic LDS beyond the 64 KB default: raise the kernel's limit once
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (attr != hipSuccess) return ick::fail(-1, "igemm: cannot reserve %zu bytes of dynamic LDS: %s", lds_bytes, hipGetErrorString(attr));
+    if (!p.ep_vec || p.splitk > 1) return ick::fail(-1, "igemm: the 256 x 256 tile needs the vector epilogue (N %% 4, ldc %% 4) and no split-K");
+    dyn = lds_bytes;
+  }
+  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>), grid, dim3(NW * 64), dyn, st, p);
   return ick::launch_status("igemm_glds");
 }
 
@@ -619,6 +657,9 @@ int launch_tile(const P& p, int nz, hipStream_t st, int tile, int m_begin = 0, i
     case 65: return launch<OP, 128, 128, 2, TERMS, 8>(p, nz, st, m_begin, m_end);     // +64: eight waves per workgroup
     case 67: return launch<OP, 128, 64, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
     case 83: return launch<OP, 128, 64, 3, TERMS, 8>(p, nz, st, m_begin, m_end);
+    case 69:      // 256 x 256 x (64 halves), eight waves as 4 x 2 (64 x 128 per wave): large plain GEMMs on native 16-bit operands
+      if constexpr (TERMS >= 5 && OP == ICK_OP_NT) return launch<OP, 256, 256, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
+      else return launch<OP, 128, 128, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
     default: return launch<OP, 128, 128, 2, TERMS>(p, nz, st, m_begin, m_end);
   }
 }

@@ -64,6 +64,23 @@ def test_linear_nt_native16(dt, M, N, K):
         assert close16(c16, torch.relu(ref + bias.double()) + res16.double(), dt), f"tile {tile}"
 
 
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(512, 512, 256), (1000, 776, 328), (2048, 1024, 4096)])
+def test_linear_nt_native16_256x256_tile(dt, M, N, K):
+    """IckGemm.tile 69: the 256 x 256 x (64 halves) workgroup tile (128 KB of dynamic LDS, two-slab epilogue), ragged M / N / K
+    tails included; bias + ReLU + residual through the same staged epilogue."""
+    from imagecaptioner_amd import ops
+    a16, b16 = ops.cast16(rnd(M, K, seed=1).cuda(), dt), ops.cast16(rnd(N, K, seed=2, scale=1 / math.sqrt(K)).cuda(), dt)
+    bias, res = rnd(N, seed=3).cuda(), rnd(M, N, seed=4).cuda()
+    ref = a16.double() @ b16.double().t()
+    c = torch.empty(M, N, device="cuda")
+    ops.gemm_raw(ops.OP_NT, a16.data_ptr(), b16.data_ptr(), c.data_ptr(), M, N, K, K, K, N, h16=dt, tile=69)
+    assert rel_err(c, ref) < 2e-5
+    ops.gemm_raw(ops.OP_NT, a16.data_ptr(), b16.data_ptr(), c.data_ptr(), M, N, K, K, K, N, h16=dt, tile=69, bias=bias.data_ptr(),
+                 act=ops.ACT_RELU, residual=res.data_ptr(), ldr=N)
+    assert rel_err(c, torch.relu(ref + bias.double()) + res.double()) < 2e-5
+
+
 CONVS = [  # (Nb, H, W, Cin, Cout, R, stride, pad): trunk geometries of layer1-4 (Cin % 32 == 0; % 64 takes the LDS-DMA kernel)
     (2, 56, 56, 64, 64, 3, 1, 1), (2, 56, 56, 64, 256, 1, 1, 0), (2, 56, 56, 256, 128, 1, 1, 0), (2, 56, 56, 128, 128, 3, 2, 1),
     (2, 56, 56, 256, 512, 1, 2, 0), (2, 28, 28, 256, 256, 3, 2, 1), (2, 14, 14, 256, 256, 3, 1, 1), (3, 14, 14, 512, 512, 3, 2, 1),

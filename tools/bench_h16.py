@@ -26,6 +26,7 @@ def timeit(f, iters=20):
 
 
 TILES = [1, 2, 3, 4, 18, 19, 65, 67, 83]
+NT_TILES = TILES + [69]          # 69: the 256 x 256 tile (native 16-bit NT only)
 print("== NT  C = A @ B^T")
 for M, N, K in [(4096, 4096, 4096), (8192, 8192, 8192), (1024, 5000, 512), (12544, 1024, 256), (12544, 256, 1024), (3136, 2048, 512)]:
     A = torch.randn(M, K, device=dev)
@@ -36,8 +37,8 @@ for M, N, K in [(4096, 4096, 4096), (8192, 8192, 8192), (1024, 5000, 512), (1254
         assert torch.equal(A16, A.to(A16.dtype)), "cast kernel differs from torch's rounding"
         ref = A16.double() @ B16.double().t() if M * N <= 4096 * 5000 else None
         line = []
-        for tile in TILES:
-            f = lambda: ops.gemm_h16_raw(ops.OP_NT, A16.data_ptr(), B16.data_ptr(), C.data_ptr(), M, N, K, K, K, N, fp16=fp16, tile=tile)
+        for tile in NT_TILES:
+            f = lambda: ops.gemm_raw(ops.OP_NT, A16.data_ptr(), B16.data_ptr(), C.data_ptr(), M, N, K, K, K, N, h16=A16.dtype, tile=tile)
             f()
             if ref is not None:
                 err = ((C.double() - ref).norm() / ref.norm()).item()
@@ -68,7 +69,7 @@ for (H, Cin, Cout, R, stride) in [(56, 64, 64, 3, 1), (28, 128, 128, 3, 1), (14,
     x16, w16 = ops.cast16(x), ops.cast16(w)
     ref = torch.nn.functional.conv2d(x16.float().permute(0, 3, 1, 2).double(), w16.float().permute(0, 3, 1, 2).double(), stride=stride, padding=pad).permute(0, 2, 3, 1)
     best = {}
-    for name, f in (("h16", lambda tile: ops.gemm_h16_raw(ops.OP_CONV_FWD, x16.data_ptr(), w16.data_ptr(), y.data_ptr(), M, N, K, Cin, K, N, conv=conv, tile=tile)),
+    for name, f in (("h16", lambda tile: ops.gemm_raw(ops.OP_CONV_FWD, x16.data_ptr(), w16.data_ptr(), y.data_ptr(), M, N, K, Cin, K, N, conv=conv, tile=tile, h16=x16.dtype)),
                     ("bf16 image", lambda tile: ops.gemm_raw(ops.OP_CONV_FWD, x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, Cin, K, N, conv=conv, tile=tile)),
                     ("f32", lambda tile: ops.gemm_raw(ops.OP_CONV_FWD, x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, Cin, K, N, conv=conv, tile=tile))):
         ctx = ops.precision("bf16" if name == "bf16 image" else "f32")
