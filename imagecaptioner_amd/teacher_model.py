@@ -189,9 +189,10 @@ class CaptioningTeacher(nn.Module):
         E, V = memory.shape[-1], self.vocab_size
         xn = self._decode_hidden(memory, captions)
         logits = ops.empty(T, B, V, device=memory.device)
-        # rows of xn are (b,t); batch the GEMM over b so that C[t][b][:] is written in place (no transpose pass)
-        ops.gemm_raw(ops.OP_NT, xn.data_ptr(), self.fc_out.weight.data_ptr(), logits.data_ptr(), T, V, E, E, E, B * V,
-                     bias=self.fc_out.bias.data_ptr(), batch=(B, 1), strides=(T * E, 0, 0, 0, V, 0))
+        # rows of xn are (b,t); batch the GEMM over t — per batch the B rows (b, t) are T*E apart — so that C[t][b][:] is
+        # written in place (no transpose pass) from full 64-row tiles (batching over b left 15-row problems: 210 us at B = 64)
+        ops.gemm_raw(ops.OP_NT, xn.data_ptr(), self.fc_out.weight.data_ptr(), logits.data_ptr(), B, V, E, T * E, E, V,
+                     bias=self.fc_out.bias.data_ptr(), batch=(T, 1), strides=(E, 0, 0, 0, B * V, 0))
         return logits
 
     @torch.no_grad()
