@@ -6,6 +6,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -150,7 +151,7 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
         d.tile = tile or _FORCE_TILE[0] or _TUNED_BF16.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
         check(_lib.lib().ick_gemm_bf16(ctypes.byref(d), terms, _st()), "ick_gemm_bf16")
         return
-    d.tile = (tile or _FORCE_TILE[0] or _TUNED.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)) | _TILE_OR[0]
+    d.tile = (tile or _FORCE_TILE[0] or _TUNED.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", default_tile)) | _TILE_OR[0]
     check(_lib.lib().ick_gemm_f32(ctypes.byref(d), _st()), "ick_gemm_f32")
 
 
@@ -355,6 +356,19 @@ def conv_out_hw(H: int, W: int, R: int, S: int, stride: int, pad: int) -> Tuple[
     return (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
 
 
+_CONV_SPLITK = [os.environ.get("ICK_CONV_SPLITK", "1") != "0"]
+
+
+def _conv_splitk(M: int, N: int, K: int) -> int:
+    """Split factor for a forward-type convolution whose grid is too small for the chip (layer4: M = 3136 pixels x 512
+    channels = 196 tiles of 64 x 128 on 256 CUs) over a long contraction.  Measured (tools/bench_conv_splitk.py, fp32):
+    3136x512x4608 216.7 -> 166.2 us at 6 splits, 3136x512x2048 102.3 -> 88.2 us; 392 tiles (12544x256) gain < 4 %: not split."""
+    if not _CONV_SPLITK[0] or K < 2048 or M < 1024:        # (tiny batches: the kernel is short anyway; keep it deterministic)
+        return 1
+    tiles = ((M + 63) // 64) * ((N + 127) // 128)
+    return 6 if tiles <= 256 else 1
+
+
 def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
              scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
              relu: bool = False, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
@@ -388,6 +402,16 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Opt
                  col_scale=scale.data_ptr(), residual=_ptr(residual), ldr=Cout,
                  act=(ACT_RELU if relu else ACT_NONE) | _lib.ACT_POST_RESIDUAL,
                  conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+        return y
+    sk = _conv_splitk(Nb * Ho * Wo, Cout, K) if (stats is not None and op == OP_CONV_FWD and _PREC[0] == "f32") else 1
+    if sk > 1:
+        # train-mode forward on a small grid: split the contraction (fp32 atomics into the zeroed output), then take the
+        # BatchNorm statistics from the finished output in one pass over its 6 MB (the epilogue cannot: it sees partial sums)
+        y.zero_()
+        gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout, splitk=sk,
+                 default_tile=4 if K >= 4096 else 2, conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+        s0, s1 = (stats[0][0], stats[1][0]) if stats[0].dim() == 2 else (stats[0], stats[1])
+        check(_lib.lib().ick_colstats(y.data_ptr(), s0.data_ptr(), s1.data_ptr(), Nb * Ho * Wo, Cout, _st()), "ick_colstats")
         return y
     gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout,
              stat_sum=_ptr(stats[0]) if stats is not None else None, stat_sq=_ptr(stats[1]) if stats is not None else None,
@@ -428,6 +452,14 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride
         # transpose of the weight per call = per step): both GEMM operands are then k-contiguous, i.e. they take the
         # LDS-DMA kernel's ds_read_b128 path instead of the strided [k][n] weight view
         wt = wt_cached if wt_cached is not None else conv_weight_dgrad_layout(w)
+        sk = _conv_splitk(Nb * H * W, Cin, K) if (h16 is None and _PREC[0] == "f32") else 1
+        if sk > 1:        # small grid, long contraction (layer4): split-K; the residual rides on split 0, `accumulate` = add onto dx
+            if not accumulate:
+                dx.zero_()
+            gemm_raw(OP_CONV_FWD, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, K, K, Cin,
+                     residual=_ptr(residual), ldr=Cin, splitk=sk, default_tile=4 if K >= 4096 else 2,
+                     conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad))
+            return dx
         gemm_raw(OP_CONV_FWD, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, K, K, Cin,
                  residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
                  conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad), **io)

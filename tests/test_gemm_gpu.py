@@ -266,3 +266,31 @@ def test_eight_wave_tiles_all_ops_vs_fp64(tile):
     finally:
         o._FORCE_TILE[0] = 0
         o._DGRAD_AS_FWD[0] = True
+
+
+def test_small_grid_convolutions_split_the_contraction():
+    """layer4 geometry at a batch where the forward-type convolutions run split-K (ops._conv_splitk: M >= 1024 rows, <= 256
+    tiles, K >= 2048): train-mode forward = fp32 atomics into the zeroed output + BatchNorm statistics from ick_colstats,
+    stride-1 data gradient with the residual on split 0 and `accumulate` adding onto dx — all against fp64."""
+    from imagecaptioner_amd import ops as o
+    Nb, H, Cin, Cout, R = 32, 7, 512, 512, 3
+    assert o._conv_splitk(Nb * H * H, Cout, R * R * Cin) > 1
+    x = rnd(Nb, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, R, R, seed=2, scale=1.0 / math.sqrt(Cin * R * R))
+    xd = x.cuda().permute(0, 2, 3, 1).contiguous()
+    wd = w.cuda().permute(0, 2, 3, 1).contiguous()
+    stats = torch.zeros(2, 3, Cout, device="cuda", dtype=torch.float64)          # three accumulator copies: colstats fills copy 0
+    y = o.conv_fwd(xd, wd, 1, 1, stats=(stats[0], stats[1]))
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    assert rel_err(y.permute(0, 3, 1, 2), ref) < 2e-5
+    assert rel_err(stats[0].sum(0), ref.sum((0, 2, 3))) < 1e-4 * max(1.0, ref.abs().sum((0, 2, 3)).max().item() / ref.sum((0, 2, 3)).abs().max().item())
+    assert rel_err(stats[1].sum(0), (ref * ref).sum((0, 2, 3))) < 1e-5
+    dy = rnd(*ref.shape, seed=3)
+    dyd = dy.cuda().permute(0, 2, 3, 1).contiguous()
+    res = rnd(Nb, H, H, Cin, seed=4).cuda()
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, w.double(), dy.double(), 1, 1) + res.cpu().double().permute(0, 3, 1, 2)
+    dx = o.conv_dgrad(dyd, wd, (H, H), 1, 1, residual=res)
+    assert rel_err(dx.permute(0, 3, 1, 2), dx_ref) < 2e-5
+    dx2 = res.clone()
+    o.conv_dgrad(dyd, wd, (H, H), 1, 1, out=dx2, accumulate=True)
+    assert rel_err(dx2.permute(0, 3, 1, 2), dx_ref) < 2e-5
