@@ -46,12 +46,13 @@ GFLOP_HOISTED = 0.85            # of the 28.4: the reference's 49x-redundant W_h
                                 # that this build hoists out of the per-position loop — counted by the contract, not executed
 
 
-def measured_traffic(batch: int):
-    """(HBM bytes per step, source file) from the newest committed PMC run (profiles/r0N_traffic.json: separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, gfx950 x2 fetch correction;
+def measured_traffic(batch: int, precision: str = "f32"):
+    """(HBM bytes per step, source file) from the newest committed PMC run of THIS precision (profiles/r0N_traffic*.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, gfx950 x2 fetch correction;
     tools/measure_traffic.py).  PMC counters cannot be collected inside the timed run itself, so the line names its
-    source; (None, None) for other batch sizes."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    source; (None, None) for other batch sizes / precisions without a committed run."""
+    names = {"f32": ("r02k_traffic.json", "r02_traffic.json", "r01_traffic.json"), "fp16": ("r02k_traffic_fp16.json",)}.get(precision, ())
+    for name in names:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
@@ -319,7 +320,7 @@ def main():
         step_ms_dev = dev_ms / args.steps
         gflop_img = GFLOP_PER_IMAGE if args.student == "cfg3" else 30.7   # cfg5 = 30.7 algorithmic GFLOP/image
         achieved = gflop_img * args.batch / step_ms_dev                   # GFLOP / ms = TFLOP/s, this rank's GPU
-        traffic, traffic_src = measured_traffic(args.batch)
+        traffic, traffic_src = measured_traffic(args.batch, args.precision)
         peak = mfma_peak(args.precision, gflop_img - GFLOP_TEACHER)
         dtype = {"f32": "f32", "bf16": "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher",
                  "fp16": "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler) + f32 teacher",
