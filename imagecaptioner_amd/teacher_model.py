@@ -148,6 +148,20 @@ class CaptioningTeacher(nn.Module):
             return vit_tokens
         return ops.linear_fwd(hnn._c(vit_tokens), self.encoder_projection.weight, self.encoder_projection.bias)
 
+    def _cross_kv_weights(self):
+        """(weight [NL*2E][E], bias [NL*2E]): the key / value rows of every layer's cross-attention in_proj, concatenated;
+        cached until one of them changes (load_state_dict bumps the version counters)."""
+        ws = [lyr.multihead_attn.in_proj_weight for lyr in self.decoder.layers]
+        bs = [lyr.multihead_attn.in_proj_bias for lyr in self.decoder.layers]
+        key = tuple((t.data_ptr(), t._version) for t in ws + bs)
+        cached = getattr(self, "_ick_cross_kv", None)
+        if cached is None or cached[0] != key:
+            E = ws[0].shape[1]
+            with torch.no_grad():
+                cached = (key, torch.cat([w[E:] for w in ws], 0).contiguous(), torch.cat([b[E:] for b in bs], 0).contiguous())
+            self._ick_cross_kv = cached
+        return cached[1], cached[2]
+
     @torch.no_grad()
     def _decode_hidden(self, memory, captions):
         """pre_output_norm(decoder(embedding + PE, memory)) for teacher-forced captions (T,B), batch-first rows
@@ -161,17 +175,23 @@ class CaptioningTeacher(nn.Module):
         Bm, L = memory.shape[0], memory.shape[1]
         assert Bm in (1, B)
         mem2 = hnn._c(memory).view(Bm * L, E)
+        # cross-attention keys / values of ALL decoder layers in one GEMM: the memory is the same for every layer, so the
+        # four [(Bm*L)][2E] projections are one [(Bm*L)][NL*2E] product over the concatenated in_proj slices (12608 x 4096 x
+        # 512 instead of 4 x 12608 x 1024 x 512: fewer, fuller rounds); layer l reads its columns in place through the
+        # attention kernel's leading dimension
+        NL = len(self.decoder.layers)
+        wkv, bkv = self._cross_kv_weights()
+        kv_all = ops.linear_fwd(mem2, wkv, bkv)                                         # [(Bm*L)][NL*2E]
         ids_bt = captions.t().contiguous()                                              # (B,T) token ids
         x2 = ops.embedding_fwd(ids_bt, self.embedding.weight, pe=self.pos_encoder.table(), per_pos=-T).view(B * T, E)
-        for lyr in self.decoder.layers:
+        for li, lyr in enumerate(self.decoder.layers):
             sa, ca = lyr.self_attn, lyr.multihead_attn
             o = self_attention(x2, B, T, H, sa.in_proj_weight, sa.in_proj_bias, causal=True)
             x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, sa.out_proj.weight, sa.out_proj.bias, residual=x2),
                                          lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, save=False)
             q = ops.linear_fwd(x2, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
-            kv = ops.linear_fwd(mem2, ca.in_proj_weight[E:], ca.in_proj_bias[E:])      # [(Bm*L)][2E]
-            o = ops.attention_fwd_fused(q, 0, E, kv, 0, 2 * E, kv, E, 2 * E, B, H, T, L, E // H, False,
-                                        kv_batch_stride=None if Bm == B else 0)
+            o = ops.attention_fwd_fused(q, 0, E, kv_all, li * 2 * E, NL * 2 * E, kv_all, li * 2 * E + E, NL * 2 * E, B, H, T, L,
+                                        E // H, False, kv_batch_stride=None if Bm == B else 0)
             x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, ca.out_proj.weight, ca.out_proj.bias, residual=x2),
                                          lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, save=False)
             h = ops.linear_fwd(x2, lyr.linear1.weight, lyr.linear1.bias, act=ACT_RELU)
