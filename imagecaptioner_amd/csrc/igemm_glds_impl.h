@@ -77,9 +77,8 @@ __device__ __forceinline__ void glds16(const float* src, unsigned lds_wave_base)
 
 // NW = waves per workgroup: 4 (2 x 2 wave grid) or 8 (4 x 2, BM = 128 only: twice the waves per SIMD behind the same LDS
 // footprint — the 128-row tiles otherwise leave 2-3 waves per SIMD to cover the per-k-tile barrier and the epilogues)
-// (tiles above 128 x 128 — the 256 x 256 tile of the native 16-bit variants — hold their two buffers in 128 KB of DYNAMIC LDS,
-//  one workgroup per CU, and keep their 128 accumulator registers per lane with the full 256-VGPR budget)
-extern __shared__ __attribute__((aligned(16))) float glds_dyn_lds[];
+// (tiles above 128 x 128 — the 256 x 256 tile of the native 16-bit variants — hold their two buffers in 128 KB of the CU's
+//  160 KB of LDS, one workgroup per CU, and keep their 128 accumulator registers per lane with the full 256-VGPR budget)
 template <int OP, int BM, int BN, int NBUF, int TERMS, int NW>
 __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_glds_kernel(const P p) {
   constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
@@ -92,9 +91,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
   constexpr int A_RPI = 64 / A_TPK, B_RPI = 64 / B_TPK;  // k-rows per DMA instruction (x-contiguous)
   constexpr bool H16OUT = TERMS != 0 && TERMS != 3;       // variants that can write C / read the residual as 16-bit (P.c16 / P.r16)
 
-  constexpr bool DYN = NBUF * BUF * 4 > 65536;          // beyond the static LDS limit: the launcher passes the size
-  __shared__ __attribute__((aligned(16))) float lds_static[DYN ? 4 : NBUF * BUF];
-  float* const lds = DYN ? glds_dyn_lds : lds_static;
+  __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -182,8 +179,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
     }
   }
 
-  const unsigned lds_base = DYN ? (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)glds_dyn_lds
-                                : (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds_static;
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
   // issue the LDS-DMA of k-tile kt into buffer buf
   auto issue = [&](int kt, int buf) {
     const int k0 = kbeg + kt * BK;
@@ -629,16 +625,7 @@ int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) 
   if ((p.c16 || p.r16) && !((TERMS != 0 && TERMS != 3) && p.ep_vec && p.splitk == 1))
     return ick::fail(-1, "igemm: a 16-bit C / residual needs a 16-bit MFMA variant of the LDS-DMA kernel, N %% 4, ldc %% 4, ldr %% 4 and no split-K");
   dim3 grid(p.tiles_n * ((p.M - m_begin + BM - 1) / BM), 1, nz);
-  constexpr size_t lds_bytes = (size_t)NBUF * (BM + BN) * BK * 4;
-  size_t dyn = 0;
-  if constexpr (lds_bytes > 65536) {       // dynamic LDS beyond the 64 KB default: raise the kernel's limit once
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (attr != hipSuccess) return ick::fail(-1, "igemm: cannot reserve %zu bytes of dynamic LDS: %s", lds_bytes, hipGetErrorString(attr));
-    if (!p.ep_vec || p.splitk > 1) return ick::fail(-1, "igemm: the 256 x 256 tile needs the vector epilogue (N %% 4, ldc %% 4) and no split-K");
-    dyn = lds_bytes;
-  }
-  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>), grid, dim3(NW * 64), dyn, st, p);
+  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>), grid, dim3(NW * 64), 0, st, p);
   return ick::launch_status("igemm_glds");
 }
 

@@ -67,7 +67,7 @@ def test_linear_nt_native16(dt, M, N, K):
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(512, 512, 256), (1000, 776, 328), (2048, 1024, 4096)])
 def test_linear_nt_native16_256x256_tile(dt, M, N, K):
-    """IckGemm.tile 69: the 256 x 256 x (64 halves) workgroup tile (128 KB of dynamic LDS, two-slab epilogue), ragged M / N / K
+    """IckGemm.tile 69: the 256 x 256 x (64 halves) workgroup tile (128 KB of LDS, two-slab epilogue), ragged M / N / K
     tails included; bias + ReLU + residual through the same staged epilogue."""
     from imagecaptioner_amd import ops
     a16, b16 = ops.cast16(rnd(M, K, seed=1).cuda(), dt), ops.cast16(rnd(N, K, seed=2, scale=1 / math.sqrt(K)).cuda(), dt)
