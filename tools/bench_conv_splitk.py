@@ -23,7 +23,11 @@ def timeit(f, iters=20):
 
 
 B = 64
-for (H, Cin, Cout, R) in [(7, 512, 512, 3), (7, 2048, 512, 1), (7, 512, 2048, 1), (14, 256, 256, 3), (14, 1024, 256, 1)]:
+SHAPES = [(7, 512, 512, 3), (7, 2048, 512, 1), (7, 512, 2048, 1), (14, 256, 256, 3), (14, 1024, 256, 1)]
+SPLITS = (1, 2, 3, 4, 6)
+if len(sys.argv) > 1 and sys.argv[1] == "layer3":          # which split counts fill whole rounds of the chip on layer3's 196 / 392 tiles
+    SHAPES, SPLITS = [(14, 256, 256, 3), (14, 1024, 256, 1), (14, 256, 1024, 1)], (1, 5, 8, 10, 13)
+for (H, Cin, Cout, R) in SHAPES:
     pad = R // 2
     x = torch.randn(B, H, H, Cin, device="cuda")
     w = torch.randn(Cout, R, R, Cin, device="cuda") * 0.05
@@ -36,7 +40,7 @@ for (H, Cin, Cout, R) in [(7, 512, 512, 3), (7, 2048, 512, 1), (7, 512, 2048, 1)
     print(f"conv M {M} N {N} K {K} ({2.0 * M * N * K / 1e9:.1f} GF)")
     for tile in (1, 2, 3, 4, 65, 67):
         line = []
-        for sk in (1, 2, 3, 4, 6):
+        for sk in SPLITS:
             def f():
                 if sk > 1:
                     y.zero_()
