@@ -292,10 +292,27 @@ def clear_weight_shadows() -> None:
     _WEIGHT_SHADOW.clear()
 
 
+_SHADOWS_CURRENT = [False]
+
+
+class weight_shadows_current:
+    """with weight_shadows_current(): ...  — the registered shadows hold THIS moment's weights (the trainer enters it for the
+    span between its per-step cast and its optimizer pass).  Outside it — validation between training steps — a shadow is one
+    AdamW update behind the master weights and is not used: the weight is cast (and cached) on use instead."""
+
+    def __enter__(self):
+        self.prev, _SHADOWS_CURRENT[0] = _SHADOWS_CURRENT[0], True
+        return self
+
+    def __exit__(self, *exc):
+        _SHADOWS_CURRENT[0] = self.prev
+        return False
+
+
 def _w16(conv: Conv2d, dt: torch.dtype) -> torch.Tensor:
     """The conv weight as [Cout][R][S][Cin] in the 16-bit storage type: the trainer's shadow, a cached copy of a frozen
     weight, or a fresh cast."""
-    sh = _WEIGHT_SHADOW.get(id(conv.weight))
+    sh = _WEIGHT_SHADOW.get(id(conv.weight)) if _SHADOWS_CURRENT[0] else None
     if sh is not None and sh[0]() is conv.weight and sh[1].dtype == dt:
         return sh[1]
     w = conv.packed()

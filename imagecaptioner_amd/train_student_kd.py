@@ -210,7 +210,7 @@ class KDTrainer:
                 self._l4_first = next(i for i, b in enumerate(blocks) if id(b) in l4)
             return out
         if self._trunk_state is not None:
-            with ops.precision(self.precision):
+            with ops.precision(self.precision), hnn.weight_shadows_current():
                 hnn.trunk_backward_stage(self._trunk_state, self._l4_first if k == 1 else 0)
             if k == 2:
                 self._trunk_state = None
@@ -248,7 +248,7 @@ class KDTrainer:
         else:
             with ops.precision(self.teacher_precision):
                 t_out = self.teacher_wrapper(self.images, cin)
-        with ops.precision(self.precision):
+        with ops.precision(self.precision), hnn.weight_shadows_current():     # (flat16 was cast at the top of this step)
             logits, enc, hids, _ = self.student(self.images, cin)
             if side is not None:
                 cur.wait_stream(side)

@@ -290,13 +290,17 @@ def test_trunk16_kd_step_runs_on_16bit_kernels_and_matches_fp32_storage_losses()
             ops.gemm_raw = orig
             assert (calls["h16"] > 100) == on, calls
             losses[on] = tr.loss_dict()
-            if on:      # the shadow the trunk read = this step's master weights, rounded
-                w = s.encoder.resnet[7][2].conv3.weight
-                sh = hnn._w16(s.encoder.resnet[7][2].conv3, torch.float16)
-                assert sh.data_ptr() != w.data_ptr() and sh.dtype == torch.float16
-                tr.train_step()
-                torch.cuda.synchronize()
-                assert torch.equal(hnn._w16(s.encoder.resnet[7][2].conv3, torch.float16), sh)
+            if on:
+                conv = s.encoder.resnet[7][2].conv3
+                with hnn.weight_shadows_current():          # inside the trainer's step: the flat 16-bit shadow, cast at its top
+                    sh = hnn._w16(conv, torch.float16)
+                lo, hi = tr.flat16.data_ptr(), tr.flat16.data_ptr() + tr.flat16.numel() * 2
+                assert lo <= sh.data_ptr() < hi and sh.dtype == torch.float16
+                # outside it (validation between steps) the shadow is one AdamW update behind: the weight is cast on use
+                now = hnn._w16(conv, torch.float16)
+                assert not (lo <= now.data_ptr() < hi)
+                assert torch.equal(now, conv.packed().contiguous().to(torch.float16))
+                assert not torch.equal(now, sh)
             del tr, s, t, p
     finally:
         ops.gemm_raw = orig
