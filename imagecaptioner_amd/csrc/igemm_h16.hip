@@ -1,8 +1,10 @@
-// igemm_h16.hip — entry of the NATIVE 16-bit GEMM variants (operands bf16 / fp16 in HBM, fp32 accumulate and fp32 output) and
-// the cast kernel that produces such operands.  The reference's autocast keeps activations and a weight copy in fp16
-// (train_student_kd.py:271): this is that storage regime for the k-contiguous contractions (Linear forward, convolution
-// forward, stride-1 data gradients run as forward convolutions).  The kernel is igemm_glds_impl.h addressed in units of two
-// halves — this file only halves the k-extents.
+// igemm_h16.hip — entry of the NATIVE 16-bit GEMM family (operands bf16 / fp16 in HBM and in LDS, fp32 accumulation, C and the
+// residual fp32 or 16-bit) and the casts that produce / consume such storage.  The reference's autocast keeps activations and a
+// weight copy in fp16 (train_student_kd.py:271): this is that storage regime for every op of the implicit-GEMM family.
+//   * both operands k-contiguous (Linear forward, convolution forward, stride-1 data gradients run as forward convolutions):
+//     the LDS-DMA kernel of igemm_glds_impl.h (TERMS 5 / 6) addressed in units of two halves — this file halves K, lda, ldb, Cin;
+//   * everything else (weight gradients, stride-2 data gradients, NN / TN): the register-staged kernel of igemm_bf16.hip with
+//     IN16 = true (8-byte fetches of four halves, transposed LDS reads).
 #include "igemm_params.h"
 
 namespace ickg {
