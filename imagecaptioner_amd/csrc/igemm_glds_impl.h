@@ -59,7 +59,20 @@ __device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
 
 constexpr int BK = 32;
 
+// Experiment knobs of the k-loop (tools/ablate/run_kloop.py builds one library per value; libick.so uses ICK_EXP_DEFAULT):
+//   1  the zero page's address is pinned in a VGPR pair (hipcc otherwise re-loads it from the GOT with s_load + lgkmcnt(0) in EVERY k-tile)
+//   2  the LDS-DMA of the next k-tile is issued in PIECES between the MFMA blocks of the first half of the k-tile instead of in
+//      one burst behind the barrier (the burst holds the wave's instruction stream for ~50 cycles per piece with the matrix pipe idle)
+//   4  s_setprio 1 across the MFMA blocks (the co-resident workgroup's address arithmetic yields to a wave that has MFMAs to issue)
+//   8  s_memtime stamps per workgroup into g_dbg (diagnostic builds only)
+#ifndef ICK_EXP
+#define ICK_EXP 0
+#endif
+
 __device__ __attribute__((aligned(16))) float g_zero16[4];   // the zero page
+#if (ICK_EXP & 8)
+__device__ long long* g_dbg = nullptr;   // diagnostic builds: 8 words per workgroup (4 s_memtime stamps, HW_ID, XCC_ID)
+#endif
 const bool g_no_vec_epilogue = [] { const char* e = getenv("ICK_NO_VEC_EPILOGUE"); return e && e[0] == '1'; }();   // A/B runs
 
 // One LDS-DMA wave-instruction: lane l's 16 bytes at `src` land at LDS byte address lds_wave_base + 16*l.
@@ -187,104 +200,88 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
   }
 
   const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)lds;
-  // issue the LDS-DMA of k-tile kt into buffer buf
-  auto issue = [&](int kt, int buf) {
-    const int k0 = kbeg + kt * BK;
-    const unsigned Ab = lds_base + 4u * (buf * BUF + wave * (PA * 256));       // LDS byte addresses (wave-uniform)
-    const unsigned Bb = lds_base + 4u * (buf * BUF + A_SZ + wave * (PB * 256));
-    if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const bool ok = a_ok[i] && (k0 + a_kq[i] < kend);
-        glds16(ok ? a_ptr[i] + k0 : g_zero16, Ab + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_FWD) {
-      const int tap = k0 / p.Cin; const int ci0 = k0 - tap * p.Cin;
-      const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int iy = a_y[i] + r, ix = a_x[i] + s;
-        const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (k0 + a_kq[i] < kend);
-        glds16(ok ? a_ptr[i] + ((long)iy * p.W + ix) * p.Cin + ci0 + a_kq[i] : g_zero16, Ab + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_FWD_C4) {
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
+  const float* zpage = g_zero16;
+  if constexpr ((ICK_EXP & 1) != 0) asm volatile("" : "+v"(zpage));   // opaque: stays in two VGPRs, never re-materialised from the GOT
+
+  // What one k-tile's DMA needs besides the per-thread state: its first k and (convolutions) the filter tap it lies in.
+  // `valid` false turns every piece into a zero-page fetch (the piecewise schedule issues unconditionally: no branches
+  // between the MFMA blocks; the epilogue drains them before it reuses the buffers).
+  struct KTile { int k0, r, s, c0, tap; bool valid; };
+  auto ktile = [&](int kt, bool valid) -> KTile {
+    KTile t; t.k0 = kbeg + kt * BK; t.r = t.s = t.c0 = t.tap = 0; t.valid = valid;
+    if constexpr (OP == ICK_OP_CONV_FWD) {
+      const int tap = t.k0 / p.Cin; t.c0 = t.k0 - tap * p.Cin; t.r = tap / p.S; t.s = tap - t.r * p.S;
+    } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
+      t.tap = t.k0 / p.Cout; t.c0 = t.k0 - t.tap * p.Cout; t.r = t.tap / p.S; t.s = t.tap - t.r * p.S;
+    } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
+      const int q = t.k0 / p.Cout; t.c0 = t.k0 - q * p.Cout;
+      t.r = r0 + 2 * (q / ns); t.s = s0 + 2 * (q % ns); t.tap = t.r * p.S + t.s;
+    }
+    return t;
+  };
+  // piece q of a k-tile's DMA into buffer buf: q < PA -> A instruction q of this wave, else B instruction q - PA
+  auto issue_piece = [&](const KTile& t, int q, int buf) {
+    const int k0 = t.k0;
+    if (q < PA) {
+      const int i = q;
+      const unsigned dst = lds_base + 4u * (buf * BUF + wave * (PA * 256)) + i * 1024;       // LDS byte address (wave-uniform)
+      bool ok; const float* src;
+      if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
+        ok = a_ok[i] && (k0 + a_kq[i] < kend); src = a_ptr[i] + k0;
+      } else if constexpr (OP == ICK_OP_CONV_FWD) {
+        const int iy = a_y[i] + t.r, ix = a_x[i] + t.s;
+        ok = a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && (k0 + a_kq[i] < kend);
+        src = a_ptr[i] + ((long)iy * p.W + ix) * p.Cin + t.c0 + a_kq[i];
+      } else if constexpr (OP == ICK_OP_CONV_FWD_C4) {
         const int tap = (k0 + a_kq[i]) >> 2; const int r = tap / p.S, s = tap - r * p.S;
         const int iy = a_y[i] + r, ix = a_x[i] + s;
-        const bool ok = a_ok[i] && r < p.R && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        glds16(ok ? a_ptr[i] + ((long)iy * p.W + ix) * 4 : g_zero16, Ab + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
-      const int tap = k0 / p.Cout; const int co0 = k0 - tap * p.Cout;
-      const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int ty = a_y[i] - r, tx = a_x[i] - s;
+        ok = a_ok[i] && r < p.R && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        src = a_ptr[i] + ((long)iy * p.W + ix) * 4;
+      } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
+        const int ty = a_y[i] - t.r, tx = a_x[i] - t.s;
         const int oy = ty / p.stride, ox = tx / p.stride;
-        const bool ok = a_ok[i] && ty >= 0 && tx >= 0 && oy * p.stride == ty && ox * p.stride == tx &&
-                        oy < p.Ho && ox < p.Wo && (k0 + a_kq[i] < kend);
-        glds16(ok ? a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co0 + a_kq[i] : g_zero16, Ab + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
-      const int q = k0 / p.Cout; const int co0 = k0 - q * p.Cout;
-      const int r = r0 + 2 * (q / ns), s = s0 + 2 * (q % ns);
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int ty = a_y[i] - r, tx = a_x[i] - s;
+        ok = a_ok[i] && ty >= 0 && tx >= 0 && oy * p.stride == ty && ox * p.stride == tx &&
+             oy < p.Ho && ox < p.Wo && (k0 + a_kq[i] < kend);
+        src = a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + t.c0 + a_kq[i];
+      } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
+        const int ty = a_y[i] - t.r, tx = a_x[i] - t.s;
         const int oy = ty >> 1, ox = tx >> 1;
-        const bool ok = a_ok[i] && ty >= 0 && tx >= 0 && oy < p.Ho && ox < p.Wo && (k0 + a_kq[i] < kend);
-        glds16(ok ? a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + co0 + a_kq[i] : g_zero16, Ab + i * 1024);
-      }
-    } else {  // A [K][M]
-#pragma unroll
-      for (int i = 0; i < PA; ++i) {
+        ok = a_ok[i] && ty >= 0 && tx >= 0 && oy < p.Ho && ox < p.Wo && (k0 + a_kq[i] < kend);
+        src = a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + t.c0 + a_kq[i];
+      } else {  // A [K][M]
         const int k = k0 + a_y[i];
-        const bool ok = a_ok[i] && k < kend;
-        glds16(ok ? a_ptr[i] + (long)k * p.lda : g_zero16, Ab + i * 1024);
+        ok = a_ok[i] && k < kend; src = a_ptr[i] + (long)k * p.lda;
       }
-    }
-    if constexpr (BKc) {
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const bool ok = b_ok[i] && (k0 + b_kq[i] < kend);
-        glds16(ok ? b_ptr[i] + k0 : g_zero16, Bb + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
-      const int tap = k0 / p.Cout; const int co0 = k0 - tap * p.Cout;
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int co = co0 + b_y[i];
-        const bool ok = b_ok[i] && (k0 + b_y[i] < kend);
-        glds16(ok ? b_ptr[i] + ((long)co * p.R * p.S + tap) * p.Cin : g_zero16, Bb + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
-      const int q = k0 / p.Cout; const int co0 = k0 - q * p.Cout;
-      const int tap = (r0 + 2 * (q / ns)) * p.S + s0 + 2 * (q % ns);
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
-        const int co = co0 + b_y[i];
-        const bool ok = b_ok[i] && (k0 + b_y[i] < kend);
-        glds16(ok ? b_ptr[i] + ((long)co * p.R * p.S + tap) * p.Cin : g_zero16, Bb + i * 1024);
-      }
-    } else if constexpr (OP == ICK_OP_CONV_WGRAD) {
-      const int hw = p.Ho * p.Wo;
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
+      glds16((ok && t.valid) ? src : zpage, dst);
+    } else {
+      const int i = q - PA;
+      const unsigned dst = lds_base + 4u * (buf * BUF + A_SZ + wave * (PB * 256)) + i * 1024;
+      bool ok; const float* src;
+      if constexpr (BKc) {
+        ok = b_ok[i] && (k0 + b_kq[i] < kend); src = b_ptr[i] + k0;
+      } else if constexpr (OP == ICK_OP_CONV_DGRAD || OP == ICK_OP_CONV_DGRAD_S2) {
+        const int co = t.c0 + b_y[i];
+        ok = b_ok[i] && (k0 + b_y[i] < kend); src = b_ptr[i] + ((long)co * p.R * p.S + t.tap) * p.Cin;
+      } else if constexpr (OP == ICK_OP_CONV_WGRAD) {
+        const int hw = p.Ho * p.Wo;
         const int k = k0 + b_y[i];
         const int b = k / hw; const int rem = k - b * hw; const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
         const int iy = oy * p.stride - p.pad + b_r, ix = ox * p.stride - p.pad + b_s;
-        const bool ok = b_ok[i] && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        glds16(ok ? b_ptr[i] + (((long)b * p.H + iy) * p.W + ix) * p.Cin : g_zero16, Bb + i * 1024);
-      }
-    } else {  // B [K][N]
-#pragma unroll
-      for (int i = 0; i < PB; ++i) {
+        ok = b_ok[i] && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        src = b_ptr[i] + (((long)b * p.H + iy) * p.W + ix) * p.Cin;
+      } else {  // B [K][N]
         const int k = k0 + b_y[i];
-        const bool ok = b_ok[i] && k < kend;
-        glds16(ok ? b_ptr[i] + (long)k * p.ldb : g_zero16, Bb + i * 1024);
+        ok = b_ok[i] && k < kend; src = b_ptr[i] + (long)k * p.ldb;
       }
+      glds16((ok && t.valid) ? src : zpage, dst);
     }
+  };
+  constexpr int NP = PA + PB;                      // DMA pieces per wave per k-tile
+  // issue the LDS-DMA of k-tile kt into buffer buf (one burst)
+  auto issue = [&](int kt, int buf) {
+    const KTile t = ktile(kt, true);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) issue_piece(t, q, buf);
   };
 
   // fragments of k-group j (8 k) of tile-row/column t: element e feeds MFMA e (k-slots {8j+e, 8j+4+e})
@@ -354,23 +351,53 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
       for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   int chain = 0;
 
+  constexpr bool IL = (ICK_EXP & 2) != 0 && TERMS == 0;   // piecewise DMA schedule (knob 2)
+  auto stamp = [&](int slot, bool on) {
+#if (ICK_EXP & 8)
+    if (on && g_dbg) {
+      const long long tm = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock
+      if (tid == 0) {
+        long long* d = g_dbg + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+        d[slot] = tm;
+        if (slot == 0) { d[6] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4); d[7] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20); }
+      }
+    }
+#endif
+  };
+  stamp(0, true);
   // NBUF = 2: DMA of tile t+1 is issued at the top of iteration t (one compute phase to land).
   // NBUF = 3: DMA of tile t+2 is issued at the top of iteration t (two compute phases to land); the wait at the top of
   //           iteration t leaves the PA+PB most recent DMAs (tile t+1) in flight.
-  if (nkt > 0) issue(0, 0);
-  if (NBUF == 3 && nkt > 1) issue(1, 1);
+  if constexpr (IL) {   // the piecewise schedule counts on NP pieces per k-tile slot being in flight, real or zero-page
+    const KTile t0 = ktile(0, nkt > 0);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) issue_piece(t0, q, 0);
+    if (NBUF == 3) {
+      const KTile t1 = ktile(1, nkt > 1);
+#pragma unroll
+      for (int q = 0; q < NP; ++q) issue_piece(t1, q, 1);
+    }
+  } else {
+    if (nkt > 0) issue(0, 0);
+    if (NBUF == 3 && nkt > 1) issue(1, 1);
+  }
   int cb = 0;                                     // buffer of tile kt
   for (int kt = 0; kt < nkt; ++kt) {
     // my DMA of tile kt has landed; after the barrier so has everybody's, and everybody is done reading the buffer
     // that the next DMA overwrites
-    if (NBUF == 3 && kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+    if (NBUF == 3 && (IL || kt + 1 < nkt)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    stamp(1, kt == 0);
+    const int nbuf = cb == 0 ? NBUF - 1 : cb - 1;   // the buffer the next DMA fills
+    KTile nxt_t = ktile(kt + NBUF - 1, kt + NBUF - 1 < nkt);
+    if constexpr (!IL) {
 #if ICK_ABL == 3
-    if (kt + NBUF - 1 < nkt && p.alpha == 12345.f) issue(kt + NBUF - 1, cb == 0 ? NBUF - 1 : cb - 1);
+      if (kt + NBUF - 1 < nkt && p.alpha == 12345.f) issue(kt + NBUF - 1, nbuf);
 #else
-    if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1, cb == 0 ? NBUF - 1 : cb - 1);
+      if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1, nbuf);
 #endif
+    }
     const float* Ab = lds + cb * BUF;
     cb = cb + 1 == NBUF ? 0 : cb + 1;
     const float* Bb = Ab + A_SZ;
@@ -396,6 +423,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
         // keep the next group's LDS reads AHEAD of this group's MFMAs (hipcc otherwise sinks them behind the MFMAs and
         // exposes the LDS latency at the head of every group)
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((ICK_EXP & 4) != 0) if (j == 0) __builtin_amdgcn_s_setprio(1);
   #pragma unroll
         for (int i = 0; i < TM; ++i)
   #pragma unroll
@@ -409,7 +437,17 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
             acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].y, bv[cur][t].y, acc[i][t], 0, 0, 0);
             acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].z, bv[cur][t].z, acc[i][t], 0, 0, 0);
             acc[i][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[cur][i].w, bv[cur][t].w, acc[i][t], 0, 0, 0);
+            if constexpr (IL) {
+              // piecewise DMA: block (j, i, t) is slot sl of 4 TM TN; the NP pieces go behind the first MFMA blocks of
+              // the k-tile, PPS per block, so that the last one still has half a k-tile of MFMAs to land under
+              constexpr int NSLOT = (BK / 8) * TM * TN, PPS = (NP + NSLOT / 2 - 1) / (NSLOT / 2);
+              const int sl = (j * TM + i) * TN + t;
+  #pragma unroll
+              for (int u = 0; u < PPS; ++u)
+                if (sl * PPS + u < NP) { __builtin_amdgcn_sched_barrier(0); issue_piece(nxt_t, sl * PPS + u, nbuf); __builtin_amdgcn_sched_barrier(0); }
+            }
           }
+        if constexpr ((ICK_EXP & 4) != 0) if (j == BK / 8 - 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         if (FB == 1 && j + 1 < BK / 8) {
   #pragma unroll
@@ -476,6 +514,8 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
 #pragma unroll
       for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t];
   }
+  if constexpr (IL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last k-tiles' zero-page pieces must land before the buffers become the C slab
+  stamp(2, true);
 
   // ---------------------------------------------------------------- epilogue
   // C/D layout of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
@@ -564,6 +604,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
       }
     }
     }
+    stamp(3, true);
     return;
   }
   auto epilogue = [&](auto full_tag) {
@@ -613,6 +654,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
   };
   if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{});
   else epilogue(std::false_type{});
+  stamp(3, true);
 }
 
 // rows [m_begin, m_end) of the problem (m_end <= 0: all of M).  A launch over a row range is what the M-split dispatch
@@ -717,16 +759,21 @@ int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
   } else
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
+    case ICK_OP_CONV_FWD: return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
+#if !(ICK_EXP & 16)   // (experiment builds instantiate NT and CONV_FWD only)
     case ICK_OP_NN: return dispatch_tile<ICK_OP_NN, TERMS>(p, nz, st, d->tile);
     case ICK_OP_TN: return dispatch_tile<ICK_OP_TN, TERMS>(p, nz, st, d->tile);
-    case ICK_OP_CONV_FWD: return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
     case ICK_OP_CONV_FWD_C4: return dispatch_tile<ICK_OP_CONV_FWD_C4, TERMS>(p, nz, st, d->tile);
     case ICK_OP_CONV_DGRAD: return dispatch_tile<ICK_OP_CONV_DGRAD, TERMS>(p, nz, st, d->tile);
     case ICK_OP_CONV_DGRAD_S2: return dispatch_tile<ICK_OP_CONV_DGRAD_S2, TERMS>(p, 4, st, d->tile);
     case ICK_OP_CONV_WGRAD:
       if constexpr (TERMS == 0) return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS>(p, nz, st, d->tile);
       else return ick::fail(-1, "ick_gemm_bf16: op %d has no LDS-DMA variant", d->op);
+#endif
     default: return ick::fail(-1, "igemm (LDS-DMA): unknown op %d", d->op);
   }
 }
+#if (ICK_EXP & 8)
+extern "C" int ick_exp_set_dbg(void* buf) { long long* b = static_cast<long long*>(buf); return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &b, sizeof(b)); }
+#endif
 }  // namespace ickg

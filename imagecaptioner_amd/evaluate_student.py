@@ -1,7 +1,7 @@
 """Evaluation after training — the "next" row N1 of SURVEY.md §8(f): the reference's StudentEvaluator
 (/root/reference/src/evaluate_student.py:21-201) on top of the device-side decoders of this package
-(student: batched greedy `CaptioningStudent.generate`; teacher: `CaptioningTeacher.caption_image` beam search on the
-HIP path).  Same class / method names and the same result-dict layout; what differs is the execution: a whole batch is
+(student: batched greedy `CaptioningStudent.generate`; teacher: `CaptioningTeacher.caption_images`, the KV-cached
+beam search batched over images on the HIP path).  Same class / method names and the same result-dict layout; what differs is the execution: a whole batch is
 decoded per launch sequence with ONE device->host copy of the token ids instead of one host sync per token per image.
 
 The metrics are host-side string arithmetic exactly as the reference defines them (they are not BLEU / METEOR proper):
@@ -73,6 +73,15 @@ class StudentEvaluator:
             toks = toks[0]
         return " ".join(toks).strip() if toks else ""
 
+    @torch.no_grad()
+    def teacher_captions(self, images: torch.Tensor, max_length: int = 25) -> List[str]:
+        """Beam-search captions of a whole batch: the KV-cached batched search (CaptioningTeacher.caption_images), one
+        device->host copy per batch instead of one decoder re-run per step per image."""
+        if hasattr(self.teacher_model, "caption_images"):
+            return [" ".join(c).strip() if c and not isinstance(c, str) else (c or "")
+                    for c in self.teacher_model.caption_images(images.to(self.device), self.vocab, max_length=max_length)]
+        return [self.teacher_caption(images[j], max_length) for j in range(images.shape[0])]
+
     def measure_inference_time(self, image: torch.Tensor, num_runs: int = 10):
         """(student seconds, teacher seconds) per caption, synchronised around the timed loops (reference :71-97)."""
         image = image.to(self.device)
@@ -117,6 +126,7 @@ class StudentEvaluator:
                 break
             k = min(imgs.size(0), per_batch, num_samples - results["total_samples"])
             s_caps = self.student_captions(imgs[:k], max_length=25)
+            t_caps = self.teacher_captions(imgs[:k], max_length=25) if self.teacher_model is not None else None
             for j in range(k):
                 ref = self.reference_caption(captions[:, j].cpu().tolist())
                 results["reference_captions"].append(ref)
@@ -126,6 +136,6 @@ class StudentEvaluator:
                     results["teacher"]["inference_times"].append(tt)
                 self._score(results["student"], s_caps[j], ref)
                 if self.teacher_model is not None:
-                    self._score(results["teacher"], self.teacher_caption(imgs[j], max_length=25), ref)
+                    self._score(results["teacher"], t_caps[j], ref)
                 results["total_samples"] += 1
         return results

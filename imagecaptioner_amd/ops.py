@@ -826,6 +826,27 @@ def beam_topk(logits: torch.Tensor, scores: torch.Tensor, k: int):
     return vals, idx
 
 
+def beam_self_attn(qkv: torch.Tensor, kcache: torch.Tensor, vcache: torch.Tensor, anc: torch.Tensor, heads: int, t: int):
+    """KV-cached self-attention of ONE new token per beam row (position t); see include/ick.h ick_beam_self_attn."""
+    rows, E3 = qkv.shape
+    E = E3 // 3
+    out = empty(rows, E, device=qkv.device)
+    check(_lib.lib().ick_beam_self_attn(_chk(qkv).data_ptr(), kcache.data_ptr(), vcache.data_ptr(), anc.data_ptr(), out.data_ptr(),
+                                        rows, E, heads, t, kcache.shape[0], _st()), "ick_beam_self_attn")
+    return out
+
+
+def beam_step(logits, score, width, seq_in, seq_out, anc_in, anc_out, next_tok, fin_seq, fin_score, fin_len, nfin, t: int,
+              end_id: int) -> None:
+    """one expansion of every image's beam, entirely on device; see include/ick.h ick_beam_step."""
+    B, W = score.shape
+    V, Tcap = logits.shape[-1], seq_in.shape[-1]
+    check(_lib.lib().ick_beam_step(_chk(logits).data_ptr(), score.data_ptr(), width.data_ptr(), seq_in.data_ptr(), seq_out.data_ptr(),
+                                   anc_in.data_ptr(), anc_out.data_ptr(), next_tok.data_ptr(), fin_seq.data_ptr(),
+                                   fin_score.data_ptr(), fin_len.data_ptr(), nfin.data_ptr(), B, W, V, Tcap, t, end_id, _st()),
+          "ick_beam_step")
+
+
 def gemm_nt(x: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Tensor, *, bias=None, residual=None,
             accumulate=False, act=ACT_NONE, splitk: int = 0, zeroed: bool = False):
     """out (M,N) = act(x (M,K) @ W^T + bias) [+ residual]; W given by raw pointer + row pitch (column slices of a

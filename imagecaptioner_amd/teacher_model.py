@@ -232,9 +232,126 @@ class CaptioningTeacher(nn.Module):
         return self.decode(memory, captions)
 
     @torch.no_grad()
+    def _beam_decode_step(self, tok, t, kc, vc, anc, kv_all, B, W, L):
+        """logits [B*W][V] of ONE new token per beam row at position t (reference :155-168 restricted to the last position):
+        self-attention over the K/V cache through the ancestry table (csrc/beam.hip), cross-attention of the W queries of
+        an image over that image's 197 memory keys (projected once for all layers and all beams), post-norm layers."""
+        E, H, NL = kv_all.shape[1] // (2 * len(self.decoder.layers)), self.num_heads, len(self.decoder.layers)
+        n = B * W
+        x2 = ops.embedding_fwd(tok, self.embedding.weight, pe=self.pos_encoder.table()[t], per_pos=n)          # (n, E)
+        for li, lyr in enumerate(self.decoder.layers):
+            sa, ca = lyr.self_attn, lyr.multihead_attn
+            qkv = ops.linear_fwd(x2, sa.in_proj_weight, sa.in_proj_bias)
+            o = ops.beam_self_attn(qkv, kc[li], vc[li], anc, H, t)
+            x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, sa.out_proj.weight, sa.out_proj.bias, residual=x2),
+                                         lyr.norm1.weight, lyr.norm1.bias, lyr.norm1.eps, save=False)
+            q = ops.linear_fwd(x2, ca.in_proj_weight[:E], ca.in_proj_bias[:E])
+            o = ops.attention_fwd_fused(q, 0, E, kv_all, li * 2 * E, NL * 2 * E, kv_all, li * 2 * E + E, NL * 2 * E, B, H, W, L,
+                                        E // H, False)
+            x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(o, ca.out_proj.weight, ca.out_proj.bias, residual=x2),
+                                         lyr.norm2.weight, lyr.norm2.bias, lyr.norm2.eps, save=False)
+            h = ops.linear_fwd(x2, lyr.linear1.weight, lyr.linear1.bias, act=ACT_RELU)
+            x2, _, _ = ops.layernorm_fwd(ops.linear_fwd(h, lyr.linear2.weight, lyr.linear2.bias, residual=x2),
+                                         lyr.norm3.weight, lyr.norm3.bias, lyr.norm3.eps, save=False)
+        xn, _, _ = ops.layernorm_fwd(x2, self.pre_output_norm.weight, self.pre_output_norm.bias, self.pre_output_norm.eps,
+                                     save=False)
+        return ops.linear_fwd(xn, self.fc_out.weight, self.fc_out.bias)
+
+    @torch.no_grad()
+    def beam_search(self, images, start_id: int, end_id, max_length: int = 20, beam_size: int = 5):
+        """Batched, KV-cached beam search over B images at once, no host synchronisation inside the loop.  Returns ONE host
+        tensor bundle {fin_seq (B,W,Tcap) int32, fin_score (B,W) raw log-prob sums, fin_len, nfin, seq, score, width}: the
+        finished hypotheses of every image in finishing order plus the beams still live after max_length steps.
+        Same search as the reference (:144-228): only beam 0 is real before the first expansion, `width` candidates survive
+        a step, a candidate ending in <END> leaves as a finished hypothesis and narrows that image's beam by one."""
+        if self.training:
+            raise NotImplementedError("the HIP teacher is forward-only/eval")
+        dev = images.device
+        B, W, V = images.shape[0], int(beam_size), self.vocab_size
+        Tcap = max_length + 1
+        memory = self.project_memory(self.encoder.forward_features(images))                     # (B,197,E)
+        L, E = memory.shape[1], memory.shape[2]
+        NL = len(self.decoder.layers)
+        wkv, bkv = self._cross_kv_weights()
+        kv_all = ops.linear_fwd(hnn._c(memory).view(B * L, E), wkv, bkv)                        # [(B*L)][NL*2E], shared by the beams
+        n = B * W
+        kc = torch.empty(NL, Tcap, n, E, dtype=torch.float32, device=dev)
+        vc = torch.empty(NL, Tcap, n, E, dtype=torch.float32, device=dev)
+        # one int32 block for everything that travels back: [fin_seq | fin_score | fin_len | nfin | width | score | seq0 | seq1]
+        sizes = [n * Tcap, n, n, B, B, n, n * Tcap, n * Tcap]
+        state = torch.zeros(sum(sizes), dtype=torch.int32, device=dev)
+        offs = [0]
+        for z in sizes:
+            offs.append(offs[-1] + z)
+        part = lambda i: state[offs[i]:offs[i + 1]]
+        fin_seq, fin_score, fin_len = part(0).view(B, W, Tcap), part(1).view(torch.float32).view(B, W), part(2).view(B, W)
+        nfin, width, score = part(3), part(4), part(5).view(torch.float32).view(B, W)
+        seq = [part(6).view(n, Tcap), part(7).view(n, Tcap)]
+        anc = [torch.zeros(Tcap, n, dtype=torch.int32, device=dev), torch.zeros(Tcap, n, dtype=torch.int32, device=dev)]
+        width.fill_(W)
+        score.fill_(float("-inf"))
+        score[:, 0] = 0.0
+        seq[0][:, 0] = start_id
+        tok = torch.full((n,), start_id, dtype=torch.int64, device=dev)
+        cur = 0
+        for t in range(max_length):
+            logits = self._beam_decode_step(tok, t, kc, vc, anc[cur], kv_all, B, W, L)
+            ops.beam_step(logits, score, width, seq[cur], seq[cur ^ 1], anc[cur], anc[cur ^ 1], tok, fin_seq, fin_score, fin_len,
+                          nfin, t, -1 if end_id is None else int(end_id))
+            cur ^= 1
+        host = state.cpu()                                                                      # the search's only device->host copy
+        hp = lambda i: host[offs[i]:offs[i + 1]]
+        return {"fin_seq": hp(0).view(B, W, Tcap), "fin_score": hp(1).view(torch.float32).view(B, W), "fin_len": hp(2).view(B, W),
+                "nfin": hp(3), "width": hp(4), "score": hp(5).view(torch.float32).view(B, W), "seq": hp(6 + cur).view(B, W, Tcap),
+                "steps": max_length}
+
+    @torch.no_grad()
+    def caption_images(self, images, vocabulary, max_length: int = 20, beam_size: int = 5, length_penalty: float = 0.6,
+                       early_stopping: bool = True, num_return_sequences: int = 1):
+        """caption_image for a batch (B,3,224,224): list (per image) of lists of strings.  The length-normalised ranking is
+        done on the host in Python floats, as the reference does it (score / ((5 + len) / 6) ** alpha, :193-197, :231-237)."""
+        self.eval()
+        device = next(self.parameters()).device
+        start_id = vocabulary.stoi.get("<START>", vocabulary.stoi.get("<UNK>"))
+        end_id = vocabulary.stoi.get("<END>", None)
+        assert start_id is not None, "Vocabulary must define <START> or <UNK>."
+        n_return = min(num_return_sequences, beam_size)
+        r = self.beam_search(hnn._c(images.to(device).float()), start_id, end_id, max_length, beam_size)
+        penalty = (lambda n: ((5.0 + n) / 6.0) ** length_penalty) if length_penalty > 0 else (lambda n: 1.0)
+        out = []
+        for b in range(images.shape[0]):
+            done = []
+            for f in range(int(r["nfin"][b])):
+                ln = int(r["fin_len"][b, f])
+                done.append((r["fin_seq"][b, f, :ln].tolist(), float(r["fin_score"][b, f]) / penalty(ln)))
+            if not done:
+                ln = r["steps"] + 1
+                done = [(r["seq"][b, j, :ln].tolist(), float(r["score"][b, j]) / penalty(ln)) for j in range(int(r["width"][b]))]
+            done.sort(key=lambda h: h[1], reverse=True)               # stable: ties keep finishing order
+            caps = []
+            for seq_, _ in done[:n_return]:
+                body = seq_[1:] if seq_ and seq_[0] == start_id else seq_
+                if end_id is not None and end_id in body:
+                    body = body[:body.index(end_id)]
+                caps.append(" ".join(vocabulary.itos[i] for i in body))
+            out.append(caps)
+        return out
+
+    @torch.no_grad()
     def caption_image(self, image, vocabulary, max_length: int = 20, beam_size: int = 5, length_penalty: float = 0.6,
                       early_stopping: bool = True, num_return_sequences: int = 1):
-        """Beam-search captioning, list of strings (reference :108-252).  Same search: every live beam is expanded
+        """Beam-search captioning of one image, list of strings (reference :108-252) — the batched search at B = 1."""
+        if image.dim() == 3:
+            image = image.unsqueeze(0)
+        return self.caption_images(image, vocabulary, max_length, beam_size, length_penalty, early_stopping,
+                                   num_return_sequences)[0]
+
+    @torch.no_grad()
+    def caption_image_recompute(self, image, vocabulary, max_length: int = 20, beam_size: int = 5, length_penalty: float = 0.6,
+                                early_stopping: bool = True, num_return_sequences: int = 1):
+        """The search exactly as the reference executes it (decoder re-run on the growing prefixes, one image, one host
+        round trip per step) — kept as the A/B and the in-tree checker of caption_images(); not used by the evaluator.
+        Beam-search captioning, list of strings (reference :108-252).  Same search: every live beam is expanded
         with log-probabilities, the `beam` best (beam, token) pairs survive, a pair ending in <END> leaves the beam
         as a finished hypothesis scored score / ((5+len)/6)^alpha (len counts <START> and <END>), and the beam width
         shrinks by the number of hypotheses that finished.  The decoder is re-run on the growing prefixes like the

@@ -173,9 +173,17 @@ class KDTrainer:
         names = {id(p): k for k, p in student.named_parameters()}
         names.update({id(p): f"projector.{k}.{n}" for k, pr in projectors.items() for n, p in pr.named_parameters()})
         self.buckets = dp.gradient_buckets(self.flat.metas, self.flat.total, names)
-        self.bucketed = (self.world > 1) if bucketed is None else bool(bucketed)
+        # bucketed=None: OFF unless ICK_DP_BUCKETED=1.  The staged step has never run on more than one GPU (no 2+ GPU box was
+        # available to this build; SCALE_r01/r02 are skipped records), so the default for world > 1 is the flat single
+        # all-reduce between the two graphs; opt in with bucketed=True / the environment variable once a multi-GPU run of
+        # tests/test_configs_gpu.py::test_two_rank_rccl_step_matches_serial_average is on record.
+        self.bucketed = (os.environ.get("ICK_DP_BUCKETED", "0") == "1" and self.world > 1) if bucketed is None else bool(bucketed)
         if len(self.buckets) != 3:
             self.bucketed = False
+        # test hook (one-GPU rehearsal of the staged step): a float s makes _reduce_bucket multiply its bucket by s on the
+        # communication stream instead of the (identity at world 1) all-reduce, so that a bucket launched before its gradients
+        # are complete, a missed or doubled range or a missing stream join changes the result.
+        self._test_bucket_scale: Optional[float] = None
         self.comm_stream = torch.cuda.Stream() if (self.bucketed and self.device.type == "cuda") else None
         # ICK_WGRAD_STREAM=1: weight gradients of the trunk on their own stream / graph branch (hnn.set_wgrad_stream).  Off by
         # default — measured: the fp32 step gets SLOWER (28.19 vs 27.58 ms: two matrix-pipe-bound GEMMs share the LDS and L2 of
@@ -218,7 +226,8 @@ class KDTrainer:
 
     def _reduce_bucket(self, k: int, boundary: bool):
         """all-reduce(SUM) of bucket k on the communication stream, behind everything the launch stream has enqueued so far."""
-        if not boundary or self.world <= 1 and self.pg is None and not torch.distributed.is_initialized():
+        if not boundary or (self._test_bucket_scale is None and self.world <= 1 and self.pg is None and
+                            not torch.distributed.is_initialized()):
             return
         a, b = self.buckets[k]
         if self.comm_stream is None:
@@ -226,7 +235,10 @@ class KDTrainer:
             return
         self.comm_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
-            dp.allreduce_gradients(self.flat.grad[a:b], self.pg, force=True)
+            if self._test_bucket_scale is not None:
+                self.flat.grad[a:b].mul_(self._test_bucket_scale)
+            else:
+                dp.allreduce_gradients(self.flat.grad[a:b], self.pg, force=True)
 
     def _forward_backward(self):
         """teacher fwd (no grad, fp32) -> student fwd -> projector -> KD loss -> backward  (reference :262-288)."""

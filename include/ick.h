@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ICK_ABI_VERSION 4
+#define ICK_ABI_VERSION 5
 
 const char* ick_last_error(void);
 int ick_abi_version(void);
@@ -234,6 +234,20 @@ int ick_dec_attn_x_bwd(const float* dX, const float* Wc2, int64_t ldwc, const fl
 int ick_transpose2d(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols, void* stream); /* dst[c][r] = src[r][c] */
 int ick_beam_topk(const float* logits, const float* scores, int Bl, int V, int k, float* out_vals, int64_t* out_idx,
                   void* stream); /* scores[b] + log_softmax(logits[b]) -> k best flat (b*V+v) candidates (teacher_model.py:170-179) */
+/* KV-cached, batched beam search (teacher_model.py:108-252 without the per-step re-run of the decoder on the whole
+ * prefix): B images x W beam slots, row = b*W + j, Tcap = max_length + 1 positions.
+ * ick_beam_self_attn: one new token per row; qkv [rows][3E] = packed in_proj of that token (position t): its key / value go
+ *   into kcache / vcache [Tcap][rows][E], the query attends to positions 0..t where position p < t is read from row
+ *   anc[p][row] (the beam's ancestor at that step: caches are never permuted).  head dim 64.
+ * ick_beam_step: per image, the `width` best of score + log_softmax(logits) over its live rows (:170-179); a pair ending in
+ *   end_id (< 0: none) leaves as a finished hypothesis (fin_seq [B][W][Tcap], fin_score raw, fin_len, nfin; :189-197), the
+ *   others are compacted into slots 0.. in rank order with their sequence (seq_in -> seq_out [rows][Tcap]), score, ancestry
+ *   (anc_in -> anc_out [Tcap][rows]) and next input token; width[b] becomes the number of survivors (:214-228). */
+int ick_beam_self_attn(const float* qkv, float* kcache, float* vcache, const int32_t* anc, float* out, int rows, int E, int heads,
+                       int t, int Tcap, void* stream);
+int ick_beam_step(const float* logits, float* score, int32_t* width, const int32_t* seq_in, int32_t* seq_out, const int32_t* anc_in,
+                  int32_t* anc_out, int64_t* next_tok, int32_t* fin_seq, float* fin_score, int32_t* fin_len, int32_t* nfin, int B,
+                  int W, int V, int Tcap, int t, int end_id, void* stream);
 
 /* ------------------------------------------------------------------ KD losses, fused forward + backward
  * DistillationLoss (distillation_utils.py:8-200).  Gradients are produced in the same pass as the loss terms,

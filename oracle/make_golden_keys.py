@@ -15,3 +15,13 @@ B16_KEYS = {   # tensor -> slice kept in the fixture (a few thousand values each
     "decoder.attention.weight": np.s_[::4, ::8], "decoder.output_projection.3.weight": np.s_[::40, ::4],
     "decoder.embedding.weight": np.s_[::40, ::4],
 }
+
+# cfg5's student (embed 384 / hidden 768 / 3 LSTM layers): the trunk slices of B16_KEYS plus its own wider / deeper heads
+CFG5_KEYS = {k: v for k, v in B16_KEYS.items() if k.startswith("encoder.resnet.")}
+CFG5_KEYS.update({
+    "encoder.projection.0.weight": np.s_[::4, ::32], "attention_refinement.attention.in_proj_weight": np.s_[::12, ::8],
+    "attention_refinement.ffn.0.weight": np.s_[::8, ::8], "decoder.lstm.weight_hh_l0": np.s_[::24, ::8],
+    "decoder.lstm.weight_ih_l1": np.s_[::24, ::8], "decoder.lstm.weight_hh_l2": np.s_[::24, ::8],
+    "decoder.attention.weight": np.s_[::4, ::8], "decoder.output_projection.3.weight": np.s_[::40, ::4],
+    "decoder.embedding.weight": np.s_[::40, ::4],
+})

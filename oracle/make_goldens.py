@@ -326,6 +326,81 @@ def golden_kd_step_b16(B=16):
     npz(f"kd_step_cfg3_B{B}.npz", **out)
 
 
+def _kd_step_reference(dt, B, dims, autocast=None):
+    """One forward + backward of the KD step through the reference's own modules (train_student_kd.py:262-288, dropout p = 0).
+    dims = (embed, hidden, layers); autocast = None or a torch dtype: the student forward, the projector and the loss then
+    run inside torch.autocast('cpu', dtype=...) exactly where the reference opens autocast('cuda') (:271-285), the teacher
+    outside of it in fp32 (:265-268)."""
+    torch.manual_seed(0)
+    torch.set_default_dtype(dt)
+    E, H, Lyr = dims
+    t = build_teacher().to(dt)
+    s = ref_student.CaptioningStudent(V, E, H, Lyr, dropout=0.3, use_attention_refinement=True)
+    apply_seeded_init(s, seed=0)
+    zero_dropout(s)
+    s.to(dt).train()
+    projectors = ref_kd.create_feature_projectors(t, s)
+    apply_seeded_init(projectors["encoder"], seed=2)
+    zero_dropout(projectors["encoder"])
+    projectors["encoder"].to(dt)
+    images, caps = synthetic_batch(B, V, T1, seed=1234)
+    cin, ctg = caps[:-1], caps[1:]
+    with torch.no_grad():
+        t_logits = t(images.to(dt), cin)
+        t_feats = t.encoder_projection(t.encoder.forward_features(images.to(dt)))
+    L = ref_kd.DistillationLoss(alpha=0.7, beta=0.2, gamma=0.1, temperature=4.0, vocab_size=V)
+    import contextlib
+    ctx = torch.autocast("cpu", dtype=autocast) if autocast is not None else contextlib.nullcontext()
+    with ctx:
+        logits, enc, hids, attw = s(images.to(dt), cin)
+        s_out = {"logits": logits, "encoder_features": enc, "hidden_states": hids}
+        t_out = {"logits": t_logits, "encoder_features": projectors["encoder"](t_feats), "hidden_states": None}
+        loss, parts = L(s_out, t_out, ctg)
+    loss.backward()
+    torch.set_default_dtype(torch.float32)
+    return s, loss, parts, logits, enc
+
+
+def golden_kd_step_b16_autocast(B=16):
+    """The AMP yardstick: the cfg3 step at B = 16 through the reference's own modules under
+    torch.autocast('cpu', bfloat16), placed where train_student_kd.py:271-285 places autocast('cuda').  CPU autocast's op
+    lists differ from CUDA's (and CPU has no fp16 autocast for every op): this is a YARDSTICK for how far a 16-bit
+    evaluation of this step lies from the fp32 one, not a pin.  Stored: the same gradient slices as kd_step_cfg3_B16.npz."""
+    out = {}
+    s, loss, parts, logits, enc = _kd_step_reference(torch.float32, B, (256, 512, 2), autocast=torch.bfloat16)
+    sd = dict(s.named_parameters())
+    out["loss_ac"] = loss.detach().float()
+    out["kd_ac"] = np.float64(parts["token_kd_loss"])
+    out["feat_ac"] = np.float64(parts["feature_kd_loss"])
+    out["logits_ac"] = logits.detach().float()[::2, :, ::25]
+    out["enc_ac"] = enc.detach().float()[:, ::4, ::4]
+    for k, sl in B16_KEYS.items():
+        out[f"g_ac:{k}"] = sd[k].grad.float()[sl]
+    print(f"  autocast bf16: loss {float(loss):.6f}")
+    npz(f"kd_step_cfg3_B{B}_autocast_bf16.npz", **out)
+
+
+from oracle.make_golden_keys import CFG5_KEYS  # noqa: E402
+
+
+def golden_kd_step_cfg5_b16(B=16):
+    """cfg5's student (embed 384 / hidden 768 / 3-layer LSTM, refinement on) + the teacher at B = 16: reference float32,
+    float64 (yardstick) and CPU-autocast bf16 gradients ('repeat the fp64 yardstick once at cfg5')."""
+    out = {}
+    for tag, dt, ac in (("f32", torch.float32, None), ("f64", torch.float64, None), ("ac", torch.float32, torch.bfloat16)):
+        s, loss, parts, logits, enc = _kd_step_reference(dt, B, (384, 768, 3), autocast=ac)
+        sd = dict(s.named_parameters())
+        out[f"loss_{tag}"] = loss.detach().double()
+        out[f"kd_{tag}"] = np.float64(parts["token_kd_loss"])
+        out[f"feat_{tag}"] = np.float64(parts["feature_kd_loss"])
+        out[f"logits_{tag}"] = logits.detach()[::2, :, ::25].to(dt)
+        out[f"enc_{tag}"] = enc.detach()[:, ::4, ::4].to(dt)
+        for k, sl in CFG5_KEYS.items():
+            out[f"g_{tag}:{k}"] = sd[k].grad.to(dt)[sl]
+        print(f"  cfg5 {tag}: loss {float(loss):.6f}")
+    npz(f"kd_step_cfg5_B{B}.npz", **out)
+
+
 # ------------------------------------------------------------------ (N4) compact student
 def golden_compact():
     """CompactCaptioningStudent (reference src/student_model_compact.py) with the MobileNetV2 stand-in: eval forward + greedy
@@ -454,6 +529,6 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "kd_step_b16", "compact", "beam", "optloss"]
     fns = {"counts": golden_param_counts, "losses": golden_losses, "projector": golden_projector,
            "refinement": golden_refinement, "decoders": golden_decoders, "cfg1": golden_cfg1,
-           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "compact": golden_compact, "beam": golden_beam, "optloss": golden_optloss}
+           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "kd_step_b16_autocast": golden_kd_step_b16_autocast, "kd_step_cfg5_b16": golden_kd_step_cfg5_b16, "compact": golden_compact, "beam": golden_beam, "optloss": golden_optloss}
     for w in which:
         fns[w]()

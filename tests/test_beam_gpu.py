@@ -116,3 +116,98 @@ def test_student_evaluator_on_synthetic_loader(teacher):
         assert batched in (single, "")          # "" only if the reference's "> 2 words" filter dropped it
         if len(single.split()) > 2:
             assert batched == single
+
+
+def test_beam_self_attn_kernel_follows_the_ancestry_table():
+    """csrc/beam.hip beam_self_attn: the new token's query attends to positions 0..t, position p < t read from row
+    anc[p][row]; the kernel also stores this step's key / value at position t.  Checked against torch on gathered caches."""
+    from imagecaptioner_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, H, E, Tcap, t = 10, 8, 512, 13, 6
+    qkv = torch.randn(rows, 3 * E, generator=g)
+    kc, vc = torch.randn(Tcap, rows, E, generator=g), torch.randn(Tcap, rows, E, generator=g)
+    anc = torch.randint(0, rows, (Tcap, rows), generator=g, dtype=torch.int32)
+    kd, vd = kc.cuda(), vc.cuda()
+    out = ops.beam_self_attn(qkv.cuda(), kd, vd, anc.cuda(), H, t).cpu()
+    assert torch.equal(kd[t].cpu(), qkv[:, E:2 * E]) and torch.equal(vd[t].cpu(), qkv[:, 2 * E:])
+    assert torch.equal(kd[:t].cpu(), kc[:t])                    # older positions untouched
+    want = torch.empty(rows, E)
+    for r in range(rows):
+        K = torch.stack([kc[p, anc[p, r]] for p in range(t)] + [qkv[r, E:2 * E]]).view(t + 1, H, 64)
+        Vv = torch.stack([vc[p, anc[p, r]] for p in range(t)] + [qkv[r, 2 * E:]]).view(t + 1, H, 64)
+        q = qkv[r, :E].view(H, 64)
+        w = torch.softmax(torch.einsum("hd,thd->ht", q.double(), K.double()) / 8.0, -1)
+        want[r] = torch.einsum("ht,thd->hd", w, Vv.double()).reshape(E).float()
+    assert (out - want).abs().max().item() < 1e-5
+
+
+def _beam_step_reference(logits, score, width, seq, t, end_id, V):
+    """the reference's expansion for one image (teacher_model.py:170-228) on host tensors"""
+    w = int(width)
+    cand = (score[:w, None] + torch.log_softmax(logits[:w], -1)).view(-1)
+    vals, flat = torch.topk(cand, w)
+    live, fin = [], []
+    for v, f in zip(vals.tolist(), flat.tolist()):
+        s = seq[f // V][:t + 1] + [f % V]
+        (fin if (end_id is not None and f % V == end_id) else live).append((s, v, f // V))
+    return live, fin
+
+
+def test_beam_step_kernel_vs_reference_expansion():
+    from imagecaptioner_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, W, V, Tcap, t, end_id = 4, 5, 5000, 9, 3, 2
+    logits = torch.randn(B * W, V, generator=g) * 2
+    logits[:, end_id] += 6.0                                     # some candidates finish
+    score = -torch.rand(B, W, generator=g) * 3
+    width = torch.tensor([5, 3, 0, 1], dtype=torch.int32)
+    seq = torch.randint(4, V, (B * W, Tcap), generator=g, dtype=torch.int32)
+    anc = torch.randint(0, B * W, (Tcap, B * W), generator=g, dtype=torch.int32)
+    d = lambda x: x.clone().cuda()
+    sc, wd, seq_in, anc_in = d(score), d(width), d(seq), d(anc)
+    seq_out, anc_out = torch.zeros_like(seq_in), torch.zeros_like(anc_in)
+    tok = torch.full((B * W,), -1, dtype=torch.int64, device="cuda")
+    fin_seq = torch.zeros(B, W, Tcap, dtype=torch.int32, device="cuda"); fin_score = torch.zeros(B, W, device="cuda")
+    fin_len = torch.zeros(B, W, dtype=torch.int32, device="cuda"); nfin = torch.tensor([0, 1, 0, 0], dtype=torch.int32, device="cuda")
+    ops.beam_step(logits.cuda(), sc, wd, seq_in, seq_out, anc_in, anc_out, tok, fin_seq, fin_score, fin_len, nfin, t, end_id)
+    torch.cuda.synchronize()
+    for b in range(B):
+        rows = slice(b * W, (b + 1) * W)
+        if int(width[b]) == 0:
+            assert int(wd[b]) == 0 and tok[rows].tolist() == [0] * W
+            continue
+        live, fin = _beam_step_reference(logits[rows], score[b], width[b], seq[rows].tolist(), t, end_id, V)
+        assert int(wd[b]) == len(live)
+        n0 = 1 if b == 1 else 0
+        assert int(nfin[b]) == n0 + len(fin)
+        for j, (s, v, origin) in enumerate(live):
+            assert seq_out[b * W + j, :t + 2].tolist() == s
+            assert abs(float(sc[b, j]) - v) < 1e-5 and int(tok[b * W + j]) == s[-1]
+            assert anc_out[:t, b * W + j].tolist() == anc[:t, b * W + origin].tolist() and int(anc_out[t, b * W + j]) == b * W + origin
+        for j, (s, v, _) in enumerate(fin):
+            assert fin_seq[b, n0 + j, :t + 2].tolist() == s and int(fin_len[b, n0 + j]) == t + 2
+            assert abs(float(fin_score[b, n0 + j]) - v) < 1e-5
+        assert tok[b * W + len(live):(b + 1) * W].tolist() == [0] * (W - len(live))
+
+
+@pytest.mark.parametrize("bias", [0.0, 10.5])
+def test_batched_cached_beam_search_equals_the_prefix_rerun_search(teacher, bias):
+    """caption_images (KV cache + ancestry table, B images x W beams per launch sequence, one device->host copy) against
+    caption_image_recompute (the reference's own procedure: the decoder re-run on the growing prefixes, one image at a
+    time): identical captions for every image, with and without early finishes."""
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    vocab = Vocab(5000)
+    images, _ = synthetic_batch(6, 5000, 16, seed=777)
+    images = images.cuda()
+    with torch.no_grad():
+        teacher.fc_out.bias[2] += bias
+    try:
+        for beam, lp, nret in ((5, 0.6, 5), (3, 0.0, 2)):
+            got = teacher.caption_images(images, vocab, max_length=14, beam_size=beam, length_penalty=lp, num_return_sequences=nret)
+            for b in range(images.shape[0]):
+                want = teacher.caption_image_recompute(images[b], vocab, max_length=14, beam_size=beam, length_penalty=lp,
+                                                       num_return_sequences=nret)
+                assert got[b] == want, (b, beam, got[b], want)
+    finally:
+        with torch.no_grad():
+            teacher.fc_out.bias[2] -= bias

@@ -393,10 +393,51 @@ def test_staged_step_on_16bit_storage_equals_single_graph_step():
     test_staged_data_parallel_step_under_an_rccl_group_equals_single_graph_step(True, precision="fp16")
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_staged_step_bucket_hook_doubles_every_gradient_exactly_once(use_graph):
+    """at world 1 the bucket all-reduce is the identity, so the rehearsal above cannot see a bucket that is
+    launched before its gradients are complete, a missed or doubled range, or a missing stream join.  Here the communication
+    stream multiplies each bucket by 2 instead (KDTrainer._test_bucket_scale): every tensor of the flat gradient buffer must
+    come out as 2x the single-graph step's gradient — 1x (written after its bucket left / range missed) or 4x (range doubled)
+    fails per tensor."""
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    B = 8
+    images, caps = synthetic_batch(B, 5000, 16, seed=3)
+    grads = {}
+    for staged in (False, True):
+        s, t, p = build_kd_models(device="cuda")
+        _no_dropout(s, p)
+        tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=B, use_graph=use_graph, bucketed=staged)
+        if staged:
+            tr._test_bucket_scale = 2.0
+            assert tr.bucketed and tr.comm_stream is not None
+        tr.train_step(images.cuda(), caps.cuda())
+        torch.cuda.synchronize()
+        grads[staged] = tr.flat.grad.clone()
+        metas = [(o, n) for _, o, n in tr.flat.metas]
+        covered = sorted(tr.buckets)
+        assert covered[0][0] == 0 and covered[-1][1] == tr.flat.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+        del tr, s, t, p
+        torch.cuda.empty_cache()
+    g0, g1 = grads[False], grads[True]
+    worst = 0.0
+    for o, n in metas:
+        a, b = g0[o:o + n].double(), g1[o:o + n].double()
+        if float(a.norm()) == 0.0:
+            assert float(b.norm()) == 0.0
+            continue
+        worst = max(worst, float((b - 2 * a).norm() / (2 * a).norm()))
+    # two evaluations of the same step differ by fp32 atomic order amplified through the train-mode trunk (~1e-2 at this batch);
+    # an unscaled tensor sits at 0.5, a twice-scaled one at 1.0
+    assert worst < 0.12, worst
+
+
+@pytest.mark.parametrize("bucketed", [False, True])
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the driver's multi-GPU node)")
-def test_two_rank_rccl_step_matches_serial_average(tmp_path):
-    """world 2 over RCCL: after one staged step both ranks hold identical parameters, and the all-reduced gradient equals
-    the sum of the two ranks' own gradients (recomputed serially on rank 0)."""
+def test_two_rank_rccl_step_matches_serial_average(tmp_path, bucketed):
+    """world 2 over RCCL, flat all-reduce (the default) and the staged bucket all-reduces: after two steps both ranks hold
+    identical parameters."""
     import subprocess
     import sys
     import os
@@ -408,8 +449,8 @@ def test_two_rank_rccl_step_matches_serial_average(tmp_path):
         "rank = int(os.environ['RANK']); torch.cuda.set_device(rank)\n"
         "dist.init_process_group('nccl', device_id=torch.device('cuda', rank))\n"
         "s, t, p = build_kd_models(device=f'cuda:{rank}')\n"
-        "tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=2, use_graph=True)\n"
-        "assert tr.bucketed and tr.world == 2\n"
+        "tr = KDTrainer(s, t, p, vocab_size=5000, batch_size=2, use_graph=True, bucketed=(os.environ.get('ICK_TEST_BUCKETED') == '1'))\n"
+        "assert tr.world == 2\n"
         "im, cp = synthetic_batch(2, 5000, 16, seed=3, rank=rank)\n"
         "tr.train_step(im.cuda(), cp.cuda()); tr.train_step(); torch.cuda.synchronize()\n"
         "chk = tr.flat.param.double().sum().reshape(1); both = [torch.zeros_like(chk) for _ in range(2)]\n"
@@ -419,7 +460,8 @@ def test_two_rank_rccl_step_matches_serial_average(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "two_rank_step.py"
     script.write_text(f"import sys; sys.path.insert(0, {root!r})\n" + code)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               ICK_TEST_BUCKETED="1" if bucketed else "0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True,
                        cwd=root, timeout=600)

@@ -97,3 +97,81 @@ def test_shard_batch():
     assert [shard_batch(512, r, 8) for r in (0, 7)] == [(0, 64), (448, 512)]
     with pytest.raises(ValueError):
         shard_batch(100, 0, 8)
+
+
+def test_global_batch_loss_with_per_shard_batchnorm_equals_average_of_shard_gradients():
+    """The statement SURVEY §8(e) / DESIGN §6 rest on, on the oracle in ONE process:
+    the gradient of the GLOBAL-batch KD loss — token KL (`batchmean` over all T*B_global rows), feature MSEs and the hidden
+    MSE + cosine term over the concatenated outputs of the shards, each shard evaluated with its OWN train-mode BatchNorm
+    statistics (per-replica BN = plain DDP) — equals the average of the per-shard gradients, which is what
+    all-reduce(SUM) / world delivers.  For the cross-entropy term (ignore_index = 0: mean over the NON-PAD targets) it does
+    not, because the shards hold different numbers of non-PAD targets; it does once each shard's CE is weighted by its share
+    of the non-PAD count — the trainer documents that it does not do that (CE weight 1 - a - b - g = 2.8e-17 in cfg3/cfg4)."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    Tn = 8
+    shapes = R.student_state_shapes(V, E, H, 1, False)
+    trainable = lambda k: not any(k.startswith(f"encoder.resnet.{i}.") for i in (0, 1, 4, 5)) and "running_" not in k
+    base = seeded_state_dict(shapes, seed=0)
+    keys = [k for k in base if trainable(k) and base[k].dtype.is_floating_point]
+
+    def fresh():
+        return {k: (v.clone().requires_grad_(True) if k in keys else v.clone()) for k, v in base.items()}
+
+    shards = []
+    for rank in range(2):
+        images, caps = synthetic_batch(2, V, Tn, seed=99, rank=rank)
+        if rank == 1:
+            caps[4:, :] = 0                                   # shard 1 holds fewer non-PAD targets than shard 0
+        g = torch.Generator().manual_seed(1000 + rank)
+        shards.append((images, caps, torch.randn(Tn - 1, 2, V, generator=g) * 2, torch.randn(2, 49, E, generator=g),
+                       [torch.randn(2, H, generator=g) for _ in range(Tn - 1)]))
+
+    def forward(sd, sh):
+        images, caps, t_logits, t_feats, t_hids = sh
+        logits, enc, hids, _ = R.student_forward(sd, images, caps[:-1], hidden=H, layers=1, refine=False, train=True)
+        return logits, enc, hids
+
+    def grads_of(loss, sd):
+        gs = torch.autograd.grad(loss, [sd[k] for k in keys], allow_unused=True, retain_graph=True)
+        return {k: (g if g is not None else torch.zeros_like(sd[k])) for k, g in zip(keys, gs)}
+
+    def terms(logits, enc, hids, t_logits, t_feats, t_hids, targets):
+        Vv = logits.shape[-1]
+        return {"kl": R.token_kd(logits, t_logits, 4.0), "feat": R.feature_kd(enc, t_feats), "hid": R.hidden_kd(hids, t_hids),
+                "ce": F.cross_entropy(logits.reshape(-1, Vv), targets.reshape(-1), ignore_index=0)}
+
+    # (1) per-shard losses, one backward each
+    per_shard = []
+    for sh in shards:
+        sd = fresh()
+        lg, en, hs = forward(sd, sh)
+        tm = terms(lg, en, hs, sh[2], sh[3], sh[4], sh[1][1:])
+        per_shard.append({name: grads_of(v, sd) for name, v in tm.items()})
+    # (2) the global-batch loss over the concatenated outputs, shards still normalised by their own BatchNorm statistics
+    sd = fresh()
+    outs = [forward(sd, sh) for sh in shards]
+    lg = torch.cat([o[0] for o in outs], dim=1)
+    en = torch.cat([o[1] for o in outs], dim=0)
+    hs = [torch.cat([o[2][t] for o in outs], dim=0) for t in range(Tn - 1)]
+    tl = torch.cat([sh[2] for sh in shards], dim=1)
+    tf = torch.cat([sh[3] for sh in shards], dim=0)
+    th = [torch.cat([sh[4][t] for sh in shards], dim=0) for t in range(Tn - 1)]
+    tg = torch.cat([sh[1][1:] for sh in shards], dim=1)
+    glob = {name: grads_of(v, sd) for name, v in terms(lg, en, hs, tl, tf, th, tg).items()}
+
+    def rel(a, b):
+        num = sum(float((a[k] - b[k]).double().pow(2).sum()) for k in keys)
+        den = sum(float(b[k].double().pow(2).sum()) for k in keys)
+        return (num / max(den, 1e-300)) ** 0.5
+
+    for name in ("kl", "feat", "hid"):
+        avg = {k: (per_shard[0][name][k] + per_shard[1][name][k]) / 2 for k in keys}
+        assert rel(avg, glob[name]) < 2e-5, (name, rel(avg, glob[name]))
+    avg = {k: (per_shard[0]["ce"][k] + per_shard[1]["ce"][k]) / 2 for k in keys}
+    assert rel(avg, glob["ce"]) > 1e-2                        # plain averaging is NOT the global CE gradient ...
+    n = [int((sh[1][1:] != 0).sum()) for sh in shards]
+    assert n[0] != n[1]
+    wavg = {k: (n[0] * per_shard[0]["ce"][k] + n[1] * per_shard[1]["ce"][k]) / (n[0] + n[1]) for k in keys}
+    assert rel(wavg, glob["ce"]) < 2e-5                       # ... weighting by the shard's non-PAD share is
