@@ -147,13 +147,17 @@ def cpu_baseline(batch: int = BATCH, budget_s: float = 20.0):
                       f"AdamW) timed separately over {len(t_opt)} steps; torch {torch.__version__} CPU eager"}
 
 
-def run_kd(args, precision, dev, rank, world, log):
+def run_kd(args, precision, dev, rank, world, log, student_cfg=None, batch=None):
     """W untimed + K timed KD train steps (hipGraph replays) at the given student precision.  Returns
-    (images/s whole job, wall seconds for K steps [max over ranks], device ms for K steps on this rank, loss dict)."""
+    (images/s whole job, wall seconds for K steps [max over ranks], device ms for K steps on this rank, loss dict).
+    student_cfg / batch default to the command line's (the extras pass cfg5 / 32)."""
     from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
     from imagecaptioner_amd.utils.seeded_init import synthetic_batch
 
-    dims = dict(embed_size=384, hidden_size=768, num_layers=3) if args.student == "cfg5" else {}
+    student_cfg = student_cfg or args.student
+    if batch is not None:
+        args = argparse.Namespace(**{**vars(args), "batch": batch})
+    dims = dict(embed_size=384, hidden_size=768, num_layers=3) if student_cfg == "cfg5" else {}
     student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev, **dims)   # identical init on every rank
     trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
                         use_graph=not args.no_graph, precision=precision, overlap_teacher=not args.no_overlap)
@@ -191,33 +195,85 @@ def run_kd(args, precision, dev, rank, world, log):
 
 
 def dominant_kernel(dev, iters=20):
-    """The single largest kernel of the step in isolation: the teacher ViT's fc1 Linear (12 launches per step,
-    igemm_f32_glds_kernel<NT,64,64>, M = 64 x 197 tokens, N = 1536, K = 384, bias + GELU fused), timed with HIP events
-    around `iters` back-to-back launches on the launch stream.  Algorithmic FLOPs = 2 M N K."""
+    """The kernel shape with the largest total time in the step, in isolation.  Candidates = the teacher ViT's three big
+    Linear shapes (12 launches per step each; profiles/r02k_step_gemm_shapes_tile_sweep.log: fc2 1983, fc1 1916, qkv 1365 us
+    per step — every other shape is below 900): each is timed with HIP events around `iters` back-to-back launches on the
+    launch stream and the one with the largest time is reported (not a hard-wired fc1).  FLOPs = 2 M N K."""
     from imagecaptioner_amd import ops
-    from imagecaptioner_amd._lib import ACT_GELU
-    M, N, K = BATCH * 197, 1536, 384
-    x = torch.randn(M, K, device=dev)
-    w = torch.randn(N, K, device=dev) * 0.05
-    b = torch.randn(N, device=dev)
-    y = torch.empty(M, N, device=dev)
-    for _ in range(3):
-        ops.linear_fwd(x, w, b, act=ACT_GELU, out=y)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        ops.linear_fwd(x, w, b, act=ACT_GELU, out=y)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / iters * 1e3
+    from imagecaptioner_amd._lib import ACT_GELU, ACT_NONE
+    M = BATCH * 197
+    best = None
+    for name, N, K, act, resid in (("ViT fc1 Linear+GELU", 1536, 384, ACT_GELU, False), ("ViT fc2 Linear+residual", 384, 1536, ACT_NONE, True),
+                                   ("ViT qkv Linear", 1152, 384, ACT_NONE, False)):
+        x = torch.randn(M, K, device=dev)
+        w = torch.randn(N, K, device=dev) * 0.05
+        b = torch.randn(N, device=dev)
+        r = torch.randn(M, N, device=dev) if resid else None
+        y = torch.empty(M, N, device=dev)
+        f = lambda: ops.linear_fwd(x, w, b, act=act, out=y, residual=r)
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        if best is None or us > best[0]:
+            best = (us, name, N, K)
+    us, name, N, K = best
     tf = 2.0 * M * N * K / us / 1e6
     tid = ops._TUNED.get(f"0:{M}:{N}:{K}:1:1", 0)
     tile = {1: "128,128", 2: "64,64", 3: "128,64", 4: "64,128", 18: "64,64,3buf", 19: "128,64,3buf", 20: "64,128,3buf"}.get(
         tid & 31, "cost-model tile") + (",8 waves" if tid & 64 else "") + (",M-split" if tid & 32 else "")
-    return {"kernel": f"igemm_f32_glds_kernel<NT,{tile}> ViT fc1 Linear+GELU 12608x1536x384 (fp32 MFMA, LDS-DMA staging, chunked accumulation)",
+    return {"kernel": f"igemm_glds_kernel<NT,{tile}> {name} {M}x{N}x{K} (fp32 MFMA, LDS-DMA staging, chunked accumulation), 12 launches per step",
             "avg_us": round(us, 1), "achieved": round(tf, 1), "peak": PEAK_F32_MFMA_TF, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F32_MFMA_TF, 4)}
+
+
+def run_beam_eval(dev, log, batch=64, beam=5, max_length=20, iters=3):
+    """cfg5's "beam=5 eval" (SURVEY 8(f) N1): the teacher's beam search (reference teacher_model.py:108-252) over a batch of
+    images with the KV-cached, batched, sync-free search (CaptioningTeacher.beam_search): ViT encode + max_length decode
+    steps of B x beam rows + one device->host copy.  Also times the reference's procedure (decoder re-run on the growing
+    prefix, one image at a time: caption_image_recompute) on 4 images for the A/B."""
+    from imagecaptioner_amd.teacher_model import CaptioningTeacher
+    from imagecaptioner_amd.utils.seeded_init import apply_seeded_init, synthetic_batch
+
+    class _V:
+        def __init__(self, n):
+            self.itos = {i: f"w{i}" for i in range(n)}
+            self.itos.update({0: "<PAD>", 1: "<START>", 2: "<END>", 3: "<UNK>"})
+            self.stoi = {w: i for i, w in self.itos.items()}
+    vocab = _V(VOCAB)
+    t = apply_seeded_init(CaptioningTeacher(VOCAB, embed_size=512, num_heads=8, num_decoder_layers=4, dropout=0.15), 1).to(dev).eval()
+    images, _ = synthetic_batch(batch, VOCAB, T1, seed=4321)
+    images = images.to(dev)
+    t.caption_images(images, vocab, max_length=max_length, beam_size=beam)
+    torch.cuda.synchronize()
+    log("[beam] timing the batched KV-cached beam search ...")
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        caps = t.caption_images(images, vocab, max_length=max_length, beam_size=beam)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    t.caption_image_recompute(images[0], vocab, max_length=max_length, beam_size=beam)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for b in range(4):
+        t.caption_image_recompute(images[b], vocab, max_length=max_length, beam_size=beam)
+    torch.cuda.synchronize()
+    dt_ref = (time.perf_counter() - t1) / 4
+    out = {"workload": f"teacher beam search, beam {beam}, max_length {max_length}, batch {batch}: ViT-S/16 encode + KV-cached decode of "
+                       f"{batch * beam} beam rows per step, on-device top-k / finishing / length bookkeeping, one D2H copy per batch",
+           "dtype": "f32", "images_per_s": round(batch / dt, 1), "beam_tokens_per_s": round(batch * beam * max_length / dt, 1),
+           "ms_per_batch": round(dt * 1e3, 2),
+           "prefix_rerun_one_image_at_a_time_images_per_s": round(1.0 / dt_ref, 2), "speedup_vs_prefix_rerun": round(dt_ref * batch / dt, 1),
+           "mean_caption_words": round(sum(len(c[0].split()) for c in caps) / len(caps), 2)}
+    del t
+    torch.cuda.empty_cache()
+    return out
 
 
 def run_cfg2(dev, log, batch=128, max_length=20, iters=10):
@@ -358,6 +414,18 @@ def main():
                                                      "final_loss": round(loss2["total_loss"], 5), "achieved_TFLOPs": round(ach2, 2),
                                                      "blended_peak_TFLOPs": round(mfma_peak(prec2), 1)}
             out["cfg2"] = run_cfg2(dev, log)
+            # cfg5's per-rank workload (large student 384/768/3 + teacher, per-GPU batch 32 of the 8-GPU global batch 256),
+            # 30.7 algorithmic GFLOP/image, and its "beam=5 eval"
+            out["cfg5_per_rank"] = {}
+            for prec5 in ("f32", "fp16"):
+                ips5, dt5, dev5, loss5 = run_kd(args, prec5, dev, rank, world, log, student_cfg="cfg5", batch=32)
+                ach5 = 30.7 * 32 / (dev5 / args.steps)
+                pk5 = mfma_peak(prec5, 30.7 - GFLOP_TEACHER)
+                out["cfg5_per_rank"][prec5] = {"workload": "cfg5 KD step: student 384/768/3-layer + ViT teacher, per-GPU batch 32", "value": round(ips5, 2),
+                                               "unit": "images/s", "ms_per_step": round(dt5 / args.steps * 1e3, 3),
+                                               "final_loss": round(loss5["total_loss"], 5), "achieved_TFLOPs": round(ach5, 2),
+                                               "peak_TFLOPs": round(pk5, 1), "frac": round(ach5 / pk5, 4)}
+            out["beam5_eval"] = run_beam_eval(dev, log)
         if world == 1 and not args.no_cpu_baseline:
             log(f"GPU: {ips:.1f} images/s; timing the CPU baseline on a bounded sample ...")
             out["cpu_baseline"] = cpu_baseline()

@@ -406,6 +406,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
     __syncthreads();
     float* ct = reinterpret_cast<float*>(lds);
     const int tid = threadIdx.x;
+    act_dispatch(post ? ICK_ACT_NONE : act, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    const bool want_stats = p.stat_sum != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nl = wn * WN + j * 32 + (lane & 31);
@@ -421,12 +424,12 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
         for (int r = 0; r < 16; ++r) {
           const int row = ml + (r & 3) + 8 * (r >> 2);
           const float v = acc[i][j][r] * alpha;
-          if (nok && m0 + row < p.M) { ssum += v; ssq = fmaf(v, v, ssq); }
+          if (want_stats && nok && m0 + row < p.M) { ssum += v; ssq = fmaf(v, v, ssq); }
           const float u = fmaf(v, csc, bias);
-          ct[row * BN + nl] = post ? u : act_fn(u, act);
+          ct[row * BN + nl] = act_c<ACT>(u);
         }
       }
-      if (p.stat_sum) {
+      if (want_stats) {
         ssum += __shfl_xor(ssum, 32);
         ssq += __shfl_xor(ssq, 32);
         if (lane < 32 && nok) {
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
         }
       }
     }
+    });
     __syncthreads();
     constexpr int C4 = BN / 4;
     for (int c = tid; c < BM * C4; c += NT) {
@@ -468,8 +472,9 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
     }
     return;
   }
-  auto epilogue = [&](auto full_tag) {
+  auto epilogue = [&](auto full_tag, auto act_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int ACT = decltype(act_tag)::value;     // compile-time activation: see igemm_params.h act_c
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WN + j * 32 + (lane & 31);
@@ -485,7 +490,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
           if (FULL || (m < p.M && nok)) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq = fmaf(v, v, ssq);
-            v = act_fn(v + bias, act);
+            v = act_c<ACT>(v + bias);
             long mr = m;
             if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
               const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
@@ -509,8 +514,16 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
       }
     }
   };
-  if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{});
-  else epilogue(std::false_type{});
+  if (act == ICK_ACT_NONE) {
+    if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{}, ActTag<ICK_ACT_NONE>{});
+    else epilogue(std::false_type{}, ActTag<ICK_ACT_NONE>{});
+  } else if (act == ICK_ACT_RELU) {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_RELU>{});
+  } else if (act == ICK_ACT_GELU) {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_GELU>{});
+  } else {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_TANH>{});
+  }
 }
 
 template <int OP, int BM, int BN, int TERMS, bool IN16>

@@ -366,10 +366,11 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
   const float* __restrict__ Rg = (p.residual && split == 0) ? p.residual + coff : nullptr;
   const float* __restrict__ biasp = (p.bias && split == 0) ? p.bias : nullptr;
   const int mode = p.splitk > 1 ? 2 : (p.accumulate ? 1 : 0);
-  const int act = p.act;
+  const int act = p.act & 15;
   const float alpha = p.alpha;
-  auto epilogue = [&](auto full_tag) {
+  auto epilogue = [&](auto full_tag, auto act_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int ACT = decltype(act_tag)::value;     // compile-time activation: see igemm_params.h act_c
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WN + j * 32 + (lane & 31);
@@ -385,7 +386,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
           if (FULL || (m < p.M && nok)) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq = fmaf(v, v, ssq);
-            v = act_fn(v + bias, act);
+            v = act_c<ACT>(v + bias);
             long mr = m;
             if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // class row -> pixel row of the full-resolution dX
               const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
@@ -409,8 +410,16 @@ __global__ __launch_bounds__(NT, 2) void igemm_f32_kernel(const P p) {
       }
     }
   };
-  if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{});
-  else epilogue(std::false_type{});
+  if (act == ICK_ACT_NONE) {
+    if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{}, ActTag<ICK_ACT_NONE>{});
+    else epilogue(std::false_type{}, ActTag<ICK_ACT_NONE>{});
+  } else if (act == ICK_ACT_RELU) {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_RELU>{});
+  } else if (act == ICK_ACT_GELU) {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_GELU>{});
+  } else {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_TANH>{});
+  }
 }
 
 template <int OP, int BM, int BN>

@@ -58,6 +58,7 @@ __device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
 }
 
 constexpr int BK = 32;
+constexpr int kCUs = 256;            // MI355X
 
 // Experiment knobs of the k-loop (tools/ablate/run_kloop.py builds one library per value; libick.so uses ICK_EXP_DEFAULT):
 //   1  the zero page's address is pinned in a VGPR pair (hipcc otherwise re-loads it from the GOT with s_load + lgkmcnt(0) in EVERY k-tile)
@@ -70,6 +71,9 @@ constexpr int BK = 32;
 #endif
 
 __device__ __attribute__((aligned(16))) float g_zero16[4];   // the zero page
+#if (ICK_EXP & 32)
+__device__ int g_stagger = 0;            // experiment: initial delay (units of 64 shader cycles) of the workgroups in odd wave slots
+#endif
 #if (ICK_EXP & 8)
 __device__ long long* g_dbg = nullptr;   // diagnostic builds: 8 words per workgroup (4 s_memtime stamps, HW_ID, XCC_ID)
 #endif
@@ -93,7 +97,10 @@ __device__ __forceinline__ void glds16(const float* src, unsigned lds_wave_base)
 // (tiles above 128 x 128 — the 256 x 256 tile of the native 16-bit variants — hold their two buffers in 128 KB of the CU's
 //  160 KB of LDS, one workgroup per CU, and keep their 128 accumulator registers per lane with the full 256-VGPR budget)
 template <int OP, int BM, int BN, int NBUF, int TERMS, int NW>
-__global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_glds_kernel(const P p) {
+// launch bounds: second argument = minimum waves per SIMD.  Two workgroups per CU for every tile up to 128 x 128: a 4-wave
+// workgroup then needs 2 (<= 256 VGPRs), an 8-wave one 4 (<= 128 VGPRs) — with 2 the eight-wave kernels silently fell to one
+// workgroup per CU once the epilogue grew past 128 registers (round 3, seen in the in-kernel stamps).
+__global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 2))) void igemm_glds_kernel(const P p) {
   constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
   constexpr int NT = NW * 64;
   constexpr int WM = BM / (NW / 2), WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -365,6 +372,17 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
 #endif
   };
   stamp(0, true);
+#if (ICK_EXP & 32)
+  // Phase stagger (experiment): the two workgroups that share a CU start together and stay in lock-step — both in their
+  // prologues, both in their epilogues, the matrix pipe idle under both.  The workgroup whose waves sit in ODD wave slots of
+  // their SIMDs sleeps for g_stagger x 64 cycles once, in the first round of the grid only: later workgroups inherit the phase
+  // of the slot they replace.
+  if (g_stagger > 0 && (long)blockIdx.z * gridDim.x + blockIdx.x < 2 * kCUs) {
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 4) & 15u;   // HW_ID[3:0] = wave id within the SIMD
+    if (wave_slot & 1u)
+      for (int i = 0; i < g_stagger; i += 16) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   // NBUF = 2: DMA of tile t+1 is issued at the top of iteration t (one compute phase to land).
   // NBUF = 3: DMA of tile t+2 is issued at the top of iteration t (two compute phases to land); the wait at the top of
   //           iteration t leaves the PA+PB most recent DMAs (tile t+1) in flight.
@@ -542,6 +560,10 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
     const int srow0 = sl * SROWS;
     __syncthreads();                       // every wave is out of the k-loop / the previous slab is stored: the LDS buffers become the C slab [SROWS][BN]
     if (SLABS == 1 || (wm * WM) / SROWS == sl) {
+    // registers -> LDS, one specialised copy per activation (igemm_params.h act_dispatch); the statistics only where asked for
+    act_dispatch(post ? ICK_ACT_NONE : act, [&](auto act_tag) {
+    constexpr int ACT = decltype(act_tag)::value;
+    const bool want_stats = p.stat_sum != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int nl = wn * WN + j * 32 + (lane & 31);
@@ -557,12 +579,12 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
         for (int r = 0; r < 16; ++r) {
           const int row = ml + (r & 3) + 8 * (r >> 2);
           const float v = acc[i][j][r] * alpha;
-          if (nok && m0 + row < p.M) { ssum += v; ssq = fmaf(v, v, ssq); }
+          if (want_stats && nok && m0 + row < p.M) { ssum += v; ssq = fmaf(v, v, ssq); }
           const float u = fmaf(v, csc, bias);
-          ct[(row - srow0) * BN + nl] = post ? u : act_fn(u, act);
+          ct[(row - srow0) * BN + nl] = act_c<ACT>(u);
         }
       }
-      if (p.stat_sum) {
+      if (want_stats) {
         ssum += __shfl_xor(ssum, 32);
         ssq += __shfl_xor(ssq, 32);
         if (lane < 32 && nok) {
@@ -571,8 +593,11 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
         }
       }
     }
+    });
     }
+    stamp(4, sl == 0);
     __syncthreads();
+    stamp(5, sl == 0);
     constexpr int C4 = BN / 4;
     for (int c = tid; c < SROWS * C4; c += NT) {
       const int row = srow0 + c / C4, col = (c % C4) * 4;
@@ -607,8 +632,9 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
     stamp(3, true);
     return;
   }
-  auto epilogue = [&](auto full_tag) {
+  auto epilogue = [&](auto full_tag, auto act_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
+    constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = n0 + wn * WN + j * 32 + (lane & 31);
@@ -624,7 +650,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
           if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL >= 4 || alpha == 12345.f)) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq = fmaf(v, v, ssq);
-            v = act_fn(v + bias, act);
+            v = act_c<ACT>(v + bias);
             long mr = m;
             if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // class row -> pixel row of the full-resolution dX
               const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
@@ -652,8 +678,18 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : 2)) void igemm_
       }
     }
   };
-  if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{});
-  else epilogue(std::false_type{});
+  // (interior tiles check-free; activations other than none / ReLU reach this dword path only with an unaligned C: they share
+  //  the boundary-checked copy)
+  if (act == ICK_ACT_NONE) {
+    if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{}, ActTag<ICK_ACT_NONE>{});
+    else epilogue(std::false_type{}, ActTag<ICK_ACT_NONE>{});
+  } else if (act == ICK_ACT_RELU) {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_RELU>{});
+  } else if (act == ICK_ACT_GELU) {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_GELU>{});
+  } else {
+    epilogue(std::false_type{}, ActTag<ICK_ACT_TANH>{});
+  }
   stamp(3, true);
 }
 
@@ -678,7 +714,6 @@ int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) 
   return ick::launch_status("igemm_glds");
 }
 
-constexpr int kCUs = 256;            // MI355X
 constexpr int kBodySlots = 2 * kCUs; // 128x128 workgroups resident at once (64 KiB of LDS each: two per CU)
 
 template <int OP, int TERMS>
@@ -773,6 +808,9 @@ int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
     default: return ick::fail(-1, "igemm (LDS-DMA): unknown op %d", d->op);
   }
 }
+#if (ICK_EXP & 32)
+extern "C" int ick_exp_set_stagger(int units) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stagger), &units, sizeof(units)); }
+#endif
 #if (ICK_EXP & 8)
 extern "C" int ick_exp_set_dbg(void* buf) { long long* b = static_cast<long long*>(buf); return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &b, sizeof(b)); }
 #endif

@@ -73,10 +73,56 @@ __device__ __forceinline__ void st4h(void* base, long idx, float4 v) {
   *reinterpret_cast<H4*>(reinterpret_cast<unsigned short*>(base) + idx) = __builtin_convertvector(f, H4);
 }
 
+// erf to < 1 ulp of fp32 (max |error| 7.6e-8 over [-6, 6], checked against scipy in double), BRANCH-FREE: both minimax
+// branches are evaluated and selected, ~25 VALU instructions.  libm's erff carries real branches that a wave takes both ways,
+// and 64 inlined copies of it per lane are what made a GELU epilogue 20 us long.
+__device__ __forceinline__ float erf_fast(float a) {
+  const float t = fabsf(a), s = a * a;
+  float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+  const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = fmaf(r, s, u);
+  r = fmaf(r, t, -1.06777877e-1f);
+  r = fmaf(r, t, -6.34846687e-1f);
+  r = fmaf(r, t, -1.28717512e-1f);
+  r = fmaf(r, t, -t);
+  const float hi = copysignf(1.0f - __expf(r), a);
+  float q = -5.96761703e-4f;
+  q = fmaf(q, s, 4.99119423e-3f);
+  q = fmaf(q, s, -2.67681349e-2f);
+  q = fmaf(q, s, 1.12819925e-1f);
+  q = fmaf(q, s, -3.76125336e-1f);
+  q = fmaf(q, s, 1.28379166e-1f);
+  const float lo = fmaf(q, a, a);
+  return t > 0.927734375f ? hi : lo;
+}
+
+// The activation as a COMPILE-TIME choice.  The epilogues are fully unrolled over the accumulator registers (16 TM TN values
+// per lane); with a run-time `act` every one of those copies carried the code of all four activations behind uniform
+// branches — ~350 instructions per element, 176 KB of sparsely executed code per kernel, and in-kernel time stamps showed a
+// 128x128 tile spending 20-38 us in its epilogue on instruction fetch (round 3, tools/ablate/run_kloop.py stamps).
+template <int ACT>
+__device__ __forceinline__ float act_c(float v) {
+  if constexpr (ACT == ICK_ACT_RELU) return v > 0.f ? v : 0.f;
+  else if constexpr (ACT == ICK_ACT_GELU) return 0.5f * v * (1.f + erf_fast(v * 0.70710678118654752440f));
+  else if constexpr (ACT == ICK_ACT_TANH) return tanhf(v);
+  else return v;
+}
+template <int ACT> struct ActTag { static constexpr int value = ACT; };
+// calls f(ActTag<act>{}): one specialised copy of the caller's unrolled loop per activation, selected by a single switch
+template <typename F>
+__device__ __forceinline__ void act_dispatch(int act, F&& f) {
+  switch (act) {
+    case ICK_ACT_RELU: f(ActTag<ICK_ACT_RELU>{}); break;
+    case ICK_ACT_GELU: f(ActTag<ICK_ACT_GELU>{}); break;
+    case ICK_ACT_TANH: f(ActTag<ICK_ACT_TANH>{}); break;
+    default: f(ActTag<ICK_ACT_NONE>{}); break;
+  }
+}
+// run-time form, for ROLLED loops only (one copy of the code)
 __device__ __forceinline__ float act_fn(float v, int act) {
-  if (act == ICK_ACT_RELU) return v > 0.f ? v : 0.f;
-  if (act == ICK_ACT_GELU) return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-  if (act == ICK_ACT_TANH) return tanhf(v);
+  if (act == ICK_ACT_RELU) return act_c<ICK_ACT_RELU>(v);
+  if (act == ICK_ACT_GELU) return act_c<ICK_ACT_GELU>(v);
+  if (act == ICK_ACT_TANH) return act_c<ICK_ACT_TANH>(v);
   return v;
 }
 

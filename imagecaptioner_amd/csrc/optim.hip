@@ -90,12 +90,16 @@ __global__ void loss_scale_update_kernel(float* __restrict__ st, float growth, f
 }
 
 __global__ void adam_bias_correction_kernel(long* __restrict__ steps, const float* __restrict__ scaler, double b1, double b2,
-                                            float* __restrict__ hyper, int n_groups, int stride) {
+                                            float* __restrict__ hyper, int n_groups, int stride,
+                                            const float* __restrict__ lr_in) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   long t = steps[0];
   if (!scaler || scaler[2] == 0.f) steps[0] = ++t; else ++t;   // skipped step: the values are unused (adamw returns early)
   const float bc1 = (float)(1.0 - pow(b1, (double)t)), bc2 = (float)(1.0 - pow(b2, (double)t));
-  for (int g = 0; g < n_groups; ++g) { hyper[g * stride + 1] = bc1; hyper[g * stride + 2] = bc2; }
+  for (int g = 0; g < n_groups; ++g) {
+    hyper[g * stride + 1] = bc1; hyper[g * stride + 2] = bc2;
+    if (lr_in) hyper[g * stride] = lr_in[g];   // this step's learning rates, uploaded as ONE contiguous block by the host
+  }
 }
 
 }  // namespace
@@ -126,11 +130,11 @@ int ick_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, 
 }
 
 int ick_adam_bias_correction(int64_t* applied_steps, const float* scaler, double beta1, double beta2, float* hyper,
-                             int n_groups, int stride, void* stream) {
+                             int n_groups, int stride, const float* lr_in, void* stream) {
   ICK_REQUIRE(applied_steps && hyper && n_groups > 0 && stride >= 3 && beta1 > 0. && beta1 < 1. && beta2 > 0. && beta2 < 1.,
               "ick_adam_bias_correction: bad arguments");
   ICK_LAUNCH(adam_bias_correction_kernel, dim3(1), dim3(64), 0, ST, (long*)applied_steps, scaler, beta1, beta2,
-             hyper, n_groups, stride);
+             hyper, n_groups, stride, lr_in);
   return ick::launch_status("adam_bias_correction");
 }
 

@@ -279,13 +279,23 @@ def _eval_coeffs(bn: BatchNorm2d) -> torch.Tensor:
 # stay fp32.  ICK_TRUNK16=0 keeps fp32 storage (the r01/r02 "fp32 image" AMP path) for A/B runs.
 _TRUNK16 = [os.environ.get("ICK_TRUNK16", "1") != "0"]
 _H16_OF = {"bf16": torch.bfloat16, "fp16": torch.float16}
-_WEIGHT_SHADOW: dict = {}     # id(parameter) -> 16-bit [Cout][R][S][Cin] copy kept current by the trainer (one flat cast per step)
+_WEIGHT_SHADOW: dict = {}     # (id(parameter), 16-bit dtype) -> 16-bit [Cout][R][S][Cin] copy kept current by a trainer (one flat cast per step)
 
 
-def install_weight_shadow(param: torch.Tensor, w16: torch.Tensor) -> None:
+def install_weight_shadow(param: torch.Tensor, w16: torch.Tensor):
     """Registers a 16-bit copy of a conv weight that the caller keeps up to date (KDTrainer: one cast of the flat
-    parameter buffer per step); conv weights without one are cast on use."""
-    _WEIGHT_SHADOW[id(param)] = (weakref.ref(param), w16)       # (the weak reference guards against a recycled id)
+    parameter buffer per step); conv weights without one are cast on use.  Keyed by parameter AND dtype (a bf16 and an fp16
+    trainer on one student do not overwrite each other); the entry goes away with the parameter, or earlier through
+    remove_weight_shadows(keys) — the owner's close().  Returns the key."""
+    key = (id(param), w16.dtype)
+    _WEIGHT_SHADOW[key] = (weakref.ref(param), w16)             # (the weak reference guards against a recycled id)
+    weakref.finalize(param, _WEIGHT_SHADOW.pop, key, None)
+    return key
+
+
+def remove_weight_shadows(keys) -> None:
+    for k in keys:
+        _WEIGHT_SHADOW.pop(k, None)
 
 
 def clear_weight_shadows() -> None:
@@ -312,8 +322,8 @@ class weight_shadows_current:
 def _w16(conv: Conv2d, dt: torch.dtype) -> torch.Tensor:
     """The conv weight as [Cout][R][S][Cin] in the 16-bit storage type: the trainer's shadow, a cached copy of a frozen
     weight, or a fresh cast."""
-    sh = _WEIGHT_SHADOW.get(id(conv.weight)) if _SHADOWS_CURRENT[0] else None
-    if sh is not None and sh[0]() is conv.weight and sh[1].dtype == dt:
+    sh = _WEIGHT_SHADOW.get((id(conv.weight), dt)) if _SHADOWS_CURRENT[0] else None
+    if sh is not None and sh[0]() is conv.weight:
         return sh[1]
     w = conv.packed()
     # cached copy: a frozen weight changes only through torch (load_state_dict -> version counter); a trainable one also by

@@ -907,11 +907,14 @@ def adamw_step(p, g, m, v, lr, betas, eps, wd, step, norm=None, max_norm=1.0, in
                                     _ptr(scaler), _st()), "ick_adamw_step")
 
 
-def adam_bias_correction(applied_steps: torch.Tensor, scaler: Optional[torch.Tensor], betas, hyper: torch.Tensor) -> None:
-    """t = ++applied_steps unless the GradScaler found inf/nan; hyper[g][1..2] = 1-beta1^t, 1-beta2^t for every row g."""
+def adam_bias_correction(applied_steps: torch.Tensor, scaler: Optional[torch.Tensor], betas, hyper: torch.Tensor,
+                         lr_in: Optional[torch.Tensor] = None) -> None:
+    """t = ++applied_steps unless the GradScaler found inf/nan; hyper[g][1..2] = 1-beta1^t, 1-beta2^t for every row g;
+    hyper[g][0] = lr_in[g] when lr_in (contiguous, one float per row) is given."""
     assert applied_steps.dtype == torch.int64 and hyper.is_contiguous()
+    assert lr_in is None or (lr_in.is_contiguous() and lr_in.numel() >= hyper.shape[0])
     check(_lib.lib().ick_adam_bias_correction(applied_steps.data_ptr(), _ptr(scaler), betas[0], betas[1], hyper.data_ptr(),
-                                              hyper.shape[0], hyper.shape[1], _st()), "ick_adam_bias_correction")
+                                              hyper.shape[0], hyper.shape[1], _ptr(lr_in), _st()), "ick_adam_bias_correction")
 
 
 def loss_scale_check(norms: torch.Tensor, state: torch.Tensor) -> None:

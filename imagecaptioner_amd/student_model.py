@@ -147,8 +147,10 @@ class DecoderFn(Function):
 
     @staticmethod
     def forward(ctx, feats, captions, dec: "LSTMDecoder", train: bool, h0, c0, *params):
-        """h0 / c0: optional caller-supplied initial state (layers, B, H) — LSTMDecoder.forward(hidden=...), reference :205,220;
-        they enter as constants (no gradient flows back into them)."""
+        """h0 / c0: optional caller-supplied initial state (layers, B, H) — LSTMDecoder.forward(hidden=...), reference :205,220.
+        A state that requires grad receives its gradient (the reference lets autograd flow into it, :205-222): dL/dh0[l] =
+        dG[l, 0] W_hh[l] (+ dhW[0] W_h for the top layer, whose state feeds step 0's attention), dL/dc0[l] = the cell
+        adjoint's carry after step 0."""
         feats = hnn._c(feats)
         captions = hnn._c(captions)
         if h0 is not None:
@@ -361,8 +363,17 @@ class DecoderFn(Function):
             ops.gemm_tn_acc(dUf2, feats2, gWa.data_ptr() + H * fs, E, E, H + E)
             ops.colsum_into(dUf2, gb(dec.attention.bias))
         ops.gemm_nn(dUf2, Wa.data_ptr() + H * fs, E, E, H + E, dfeats.view(B * P, E), accumulate=True)
+        dh0 = dc0 = None
+        if h0 is not None and (ctx.needs_input_grad[4] or ctx.needs_input_grad[5]):
+            dh0 = ops.zeros(NL, B, H, device=dev)
+            for l in range(NL):
+                _, wh, _, _ = dec.lstm.layer(l)
+                ops.gemm_nn(DG[l, 0], wh.data_ptr(), 4 * H, H, H, dh0[l], zeroed=True)
+            ops.gemm_nn(dhW[0], Wa.data_ptr(), E, H, H + E, dh0[NL - 1], accumulate=True)
+            carries = carry_c                                       # after step 0 each holds dL/dc(-1) = dL/dc0
+            dc0 = torch.stack([hnn._c(cc) for cc in carries], 0)
         ctx.saved = None
-        return (dfeats,) + (None,) * (len(ctx.needs_input_grad) - 1)
+        return (dfeats, None, None, None, dh0, dc0) + (None,) * (len(ctx.needs_input_grad) - 6)
 
 
 class LSTMDecoder(nn.Module):

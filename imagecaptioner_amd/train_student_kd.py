@@ -142,7 +142,8 @@ class KDTrainer:
         # steps (ick_adam_bias_correction inside the optimizer graph): a step the GradScaler skips does not advance t,
         # exactly like torch's scaler.step(optimizer).
         cuda = self.device.type == "cuda"
-        self._hyper_ring = [torch.zeros(4, 4, dtype=torch.float32).pin_memory() if cuda else torch.zeros(4, 4) for _ in range(8)]
+        self._hyper_ring = [torch.zeros(4, dtype=torch.float32).pin_memory() if cuda else torch.zeros(4) for _ in range(8)]
+        self.lr_dev = torch.zeros(4, dtype=torch.float32, device=self.device)      # this step's LR per group, contiguous
         self._hyper_events = [None] * len(self._hyper_ring)
         self._hyper_slot = 0
         self.applied_steps_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
@@ -192,6 +193,7 @@ class KDTrainer:
         # 16-bit training regime (hnn._TRUNK16): the trunk reads bf16 / fp16 weights.  One cast of the encoder segment of the
         # flat parameter buffer per step keeps a flat 16-bit shadow current; every trainable conv weight gets a view of it.
         self.flat16 = None
+        self._shadow_keys = []
         dt16 = hnn._H16_OF.get(precision)
         if dt16 is not None and hnn._TRUNK16[0] and cuda:
             a, b = self.flat.segment("encoder")
@@ -199,10 +201,22 @@ class KDTrainer:
             for p, o, n in self.flat.metas:
                 if p.dim() == 4 and o + n <= b:
                     co, ci, r, s_ = p.shape
-                    hnn.install_weight_shadow(p, self.flat16[o:o + n].view(co, r, s_, ci))
+                    self._shadow_keys.append(hnn.install_weight_shadow(p, self.flat16[o:o + n].view(co, r, s_, ci)))
         self.g_stage: List[Optional[torch.cuda.CUDAGraph]] = [None, None, None]
         self._trunk_state = None
         self._l4_first = None
+
+    def close(self) -> None:
+        """Drops what this trainer registered outside itself (the 16-bit weight shadows: nn._WEIGHT_SHADOW would otherwise keep
+        flat16 alive after the trainer is gone).  Called by __del__; idempotent."""
+        hnn.remove_weight_shadows(getattr(self, "_shadow_keys", ()))
+        self._shadow_keys = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ------------------------------------------------------------------ the step body
     def _stage(self, k: int):
@@ -294,7 +308,7 @@ class KDTrainer:
             ops.grad_norm(f.grad[pa:pb], self.ws, self.norms[1:2])
         if self.scaler is not None:
             ops.loss_scale_check(self.norms, self.scaler)
-        ops.adam_bias_correction(self.applied_steps_dev, self.scaler, self.betas, self.hyper)
+        ops.adam_bias_correction(self.applied_steps_dev, self.scaler, self.betas, self.hyper, self.lr_dev)
         for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
             a, b = f.segment(name)
             if b <= a:
@@ -317,9 +331,10 @@ class KDTrainer:
         for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
             # the scheduler is stepped AFTER optimizer.step() in the reference (:299-303): step k uses the LR set at k-1
             base = self.lr * self.group_lr_mult[name]
-            host[gi, 0] = self.eta_min + (base - self.eta_min) * self._f_now
-        # only the LR column travels (strided view of the device tensor): columns 1-2 belong to the device-side counter
-        self.hyper[:, 0].copy_(host[:, 0], non_blocking=True)
+            host[gi] = self.eta_min + (base - self.eta_min) * self._f_now
+        # ONE contiguous pinned -> device copy (a strided copy would be staged through a pageable temporary and block the
+        # host); ick_adam_bias_correction scatters lr_dev into the hyper rows inside the optimizer graph
+        self.lr_dev.copy_(host, non_blocking=True)
         if self.device.type == "cuda":
             ev = torch.cuda.Event()
             ev.record()
@@ -372,6 +387,7 @@ class KDTrainer:
     def _optimizer_dry(self):
         """warm-up call of the optimizer kernels that leaves parameters untouched (lr = 0, moments restored)."""
         self.hyper.zero_()           # lr = 0 (the bias-correction columns are rewritten by the device-side counter)
+        self.lr_dev.zero_()
         m, v = self.flat.exp_avg.clone(), self.flat.exp_avg_sq.clone()
         wd, self.wd = self.wd, 0.0
         self._optimizer()

@@ -33,15 +33,20 @@ def test_decoder_with_caller_supplied_initial_state(E, H, NL):
     h0, c0 = torch.randn(NL, B, H, generator=g) * 0.5, torch.randn(NL, B, H, generator=g) * 0.5
     sd = {"decoder." + k: v.detach().double().cpu().requires_grad_(v.dtype.is_floating_point) for k, v in dec.state_dict().items()}
     f64 = feats.double().requires_grad_(True)
-    want, hids, attw = R.lstm_decoder(sd, f64, caps, NL, H, init=(h0.double(), c0.double()))
+    h64, c64 = h0.double().requires_grad_(True), c0.double().requires_grad_(True)
+    want, hids, attw = R.lstm_decoder(sd, f64, caps, NL, H, init=(h64, c64))
     dl = torch.randn(T, B, V, generator=g) * 1e-2
     want.backward(dl.double())
     fd = feats.cuda().requires_grad_(True)
     dec.train()                                                     # dropout p = 0: train mode keeps the backward records
-    got, ghids, gattw = dec(fd, caps.cuda(), hidden=(h0.cuda(), c0.cuda()))
+    hd, cd = h0.cuda().requires_grad_(True), c0.cuda().requires_grad_(True)
+    got, ghids, gattw = dec(fd, caps.cuda(), hidden=(hd, cd))
     assert rel(got, want) < 2e-5 and rel(ghids[-1], hids[-1]) < 2e-5 and rel(gattw[0], attw[0]) < 2e-5
     got.backward(dl.cuda())
     assert rel(fd.grad, f64.grad) < 2e-4
+    # the gradient INTO the caller's state (the reference lets autograd flow into `hidden`, :205-222)
+    assert hd.grad is not None and cd.grad is not None
+    assert rel(hd.grad, h64.grad) < 2e-4 and rel(cd.grad, c64.grad) < 2e-4
     for k in ("lstm.weight_hh_l0", "attention.weight", "lstm.weight_ih_l0", "embedding.weight"):
         assert rel(dict(dec.named_parameters())[k].grad, sd["decoder." + k].grad) < 2e-4, k
     # zero state given explicitly == no state given

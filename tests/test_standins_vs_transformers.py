@@ -102,3 +102,44 @@ def test_vit_s16_standin_equals_transformers_vit():
         got = hf(x).last_hidden_state
     assert got.shape == want.shape == (2, 197, 384)
     assert _rel(got, want) < 1e-5
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_mobilenet_v2_standin_equals_transformers_mobilenet_v2(train):
+    """The compact student's backbone (row N4; reference student_model_compact.py:19-22 slices torchvision's
+    `mobilenet_v2(...).features`): the stand-in against transformers.MobileNetV2Model built from a config object with
+    torchvision's conventions (no TF padding, BatchNorm eps 1e-5) — same 2,223,872 parameters, outputs equal at 1e-5."""
+    from transformers import MobileNetV2Config, MobileNetV2Model
+    torch.manual_seed(0)
+    ours = apply_seeded_init(standins.MobileNetV2(), 13)
+    cfg = MobileNetV2Config(tf_padding=False, layer_norm_eps=1e-5)
+    hf = MobileNetV2Model(cfg, add_pooling_layer=False)
+    feats = ours.features
+    assert sum(p.numel() for p in feats.parameters()) == sum(p.numel() for p in hf.parameters()) == 2223872
+    sd = feats.state_dict()
+    mapped = {}
+
+    def put(dst, src_conv, src_bn):
+        mapped[dst + ".convolution.weight"] = sd[src_conv + ".weight"]
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            mapped[dst + ".normalization." + s] = sd[src_bn + "." + s]
+
+    put("conv_stem.first_conv", "0.0", "0.1")
+    put("conv_stem.conv_3x3", "1.conv.0.0", "1.conv.0.1")            # t = 1 block: depthwise then project
+    put("conv_stem.reduce_1x1", "1.conv.1", "1.conv.2")
+    for i in range(16):
+        f = f"{i + 2}.conv."
+        put(f"layer.{i}.expand_1x1", f + "0.0", f + "0.1")
+        put(f"layer.{i}.conv_3x3", f + "1.0", f + "1.1")
+        put(f"layer.{i}.reduce_1x1", f + "2", f + "3")
+    put("conv_1x1", "18.0", "18.1")
+    missing, unexpected = hf.load_state_dict(mapped, strict=False)
+    assert not unexpected and not [m for m in missing if "num_batches_tracked" not in m], (missing, unexpected)
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(7))
+    feats.train(train)
+    hf.train(train)
+    with torch.no_grad():
+        want = feats(x)
+        got = hf(x).last_hidden_state
+    assert got.shape == want.shape == (2, 1280, 7, 7)
+    assert _rel(got, want) < 1e-5

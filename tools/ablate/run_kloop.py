@@ -91,43 +91,66 @@ def main():
                     line += f"  {t * 1e6:7.1f} ({2.0 * M * N * K / t / 1e12:5.1f}){same}"
                 print(line, flush=True)
         return
+    if mode == "stagger":          # libraries built with knob 32: initial delay of the odd-wave-slot workgroups, in microseconds
+        L = libs[ns[0]]
+        print("stagger sweep, ICK_EXP", ns[0], "; columns = delay in us of the odd-slot workgroups of the first round", flush=True)
+        delays = [0, 3, 6, 9, 12, 16, 20, 26]
+        for name, op, M, N, K, conv, act in CASES:
+            for tile in (1, 65, 4, 2):
+                d = desc(torch, IckGemm, bufs, op, M, N, K, conv, act, tile, y)
+                line = f"{name:26s} tile {tile:3d}"
+                for us_ in delays:
+                    assert L.ick_exp_set_stagger(int(us_ * 2100 / 64)) == 0      # ~2.1 GHz under load
+                    t = timeit(lambda: L.ick_gemm_f32(ctypes.byref(d), st))
+                    line += f"  {us_:2d}us {t * 1e6:6.1f}"
+                print(line, flush=True)
+        return
     # stamps
     import numpy as np
     for n in ns:
         L = libs[n]
-        for name, op, M, N, K, conv, act in CASES[:3] + CASES[5:6]:
+        for stag_us in ((0, 10) if hasattr(L, "ick_exp_set_stagger") else (0,)):
+          if hasattr(L, "ick_exp_set_stagger"):
+              assert L.ick_exp_set_stagger(int(stag_us * 2100 / 64)) == 0
+              print(f"==== stagger {stag_us} us", flush=True)
+          for name, op, M, N, K, conv, act in CASES[:3] + CASES[5:6]:
             for tile in (1, 65):
-                dbg = torch.zeros(8 * 65536, dtype=torch.int64, device="cuda")
-                assert L.ick_exp_set_dbg(ctypes.c_void_p(dbg.data_ptr())) == 0
-                d = desc(torch, IckGemm, bufs, op, M, N, K, conv, act, tile, y)
-                for _ in range(3):
-                    L.ick_gemm_f32(ctypes.byref(d), st)
-                torch.cuda.synchronize()
-                a = dbg.cpu().numpy().reshape(-1, 8)
-                a = a[a[:, 0] != 0]
-                t0 = a[:, 0].min()
-                clk = 100e6                                           # s_memrealtime: 100 MHz
-                us = lambda v: v / clk * 1e6
-                pro, kl, ep = us(a[:, 1] - a[:, 0]), us(a[:, 2] - a[:, 1]), us(a[:, 3] - a[:, 2])
-                start, end = us(a[:, 0] - t0), us(a[:, 3] - t0)
-                hw, xcc = a[:, 6], a[:, 7]
-                cu = ((xcc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
-                print(f"EXP {n} {name} tile {tile}: {len(a)} workgroups on {len(np.unique(cu))} CUs, span {end.max():.1f} us; per-workgroup "
-                      f"prologue {np.median(pro):.2f} (p90 {np.percentile(pro, 90):.2f})  k-loop {np.median(kl):.2f} (p10 {np.percentile(kl, 10):.2f} "
-                      f"p90 {np.percentile(kl, 90):.2f})  epilogue {np.median(ep):.2f} (p90 {np.percentile(ep, 90):.2f}) us", flush=True)
-                # per CU: how much of the span has 0 / 1 / 2+ workgroups inside their k-loops
-                grid = np.linspace(0, end.max(), 2001)
-                k0, k1 = us(a[:, 1] - t0), us(a[:, 2] - t0)
-                occ = np.zeros((3,))
-                for c in np.unique(cu):
-                    m = cu == c
-                    cnt = ((k0[m][:, None] <= grid[None, :]) & (grid[None, :] < k1[m][:, None])).sum(0)
-                    for v in range(3):
-                        occ[v] += (np.minimum(cnt, 2) == v).mean()
-                occ /= len(np.unique(cu))
-                rounds = np.sort(start)
-                print(f"      share of the span with 0 / 1 / 2 workgroups of a CU in their k-loop: {occ[0]:.2f} / {occ[1]:.2f} / {occ[2]:.2f};"
-                      f" starts at {np.percentile(start, [0, 25, 50, 75, 100]).round(1)} us", flush=True)
+                  dbg = torch.zeros(8 * 65536, dtype=torch.int64, device="cuda")
+                  assert L.ick_exp_set_dbg(ctypes.c_void_p(dbg.data_ptr())) == 0
+                  d = desc(torch, IckGemm, bufs, op, M, N, K, conv, act, tile, y)
+                  for _ in range(3):
+                      L.ick_gemm_f32(ctypes.byref(d), st)
+                  torch.cuda.synchronize()
+                  a = dbg.cpu().numpy().reshape(-1, 8)
+                  a = a[a[:, 0] != 0]
+                  t0 = a[:, 0].min()
+                  clk = 100e6                                           # s_memrealtime: 100 MHz
+                  us = lambda v: v / clk * 1e6
+                  pro, kl, ep = us(a[:, 1] - a[:, 0]), us(a[:, 2] - a[:, 1]), us(a[:, 3] - a[:, 2])
+                  start, end = us(a[:, 0] - t0), us(a[:, 3] - t0)
+                  if (a[:, 4] != 0).all():
+                      e1, e2, e3 = us(a[:, 4] - a[:, 2]), us(a[:, 5] - a[:, 4]), us(a[:, 3] - a[:, 5])
+                      print(f"      epilogue split (thread 0): barrier + registers->LDS {np.median(e1):.2f} (p90 {np.percentile(e1, 90):.2f})  "
+                            f"second barrier {np.median(e2):.2f} (p90 {np.percentile(e2, 90):.2f})  LDS->global stores issued "
+                            f"{np.median(e3):.2f} (p90 {np.percentile(e3, 90):.2f}) us", flush=True)
+                  hw, xcc = a[:, 6], a[:, 7]
+                  cu = ((xcc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
+                  print(f"EXP {n} {name} tile {tile}: {len(a)} workgroups on {len(np.unique(cu))} CUs, span {end.max():.1f} us; per-workgroup "
+                        f"prologue {np.median(pro):.2f} (p90 {np.percentile(pro, 90):.2f})  k-loop {np.median(kl):.2f} (p10 {np.percentile(kl, 10):.2f} "
+                        f"p90 {np.percentile(kl, 90):.2f})  epilogue {np.median(ep):.2f} (p90 {np.percentile(ep, 90):.2f}) us", flush=True)
+                  # per CU: how much of the span has 0 / 1 / 2+ workgroups inside their k-loops
+                  grid = np.linspace(0, end.max(), 2001)
+                  k0, k1 = us(a[:, 1] - t0), us(a[:, 2] - t0)
+                  occ = np.zeros((3,))
+                  for c in np.unique(cu):
+                      m = cu == c
+                      cnt = ((k0[m][:, None] <= grid[None, :]) & (grid[None, :] < k1[m][:, None])).sum(0)
+                      for v in range(3):
+                          occ[v] += (np.minimum(cnt, 2) == v).mean()
+                  occ /= len(np.unique(cu))
+                  rounds = np.sort(start)
+                  print(f"      share of the span with 0 / 1 / 2 workgroups of a CU in their k-loop: {occ[0]:.2f} / {occ[1]:.2f} / {occ[2]:.2f};"
+                        f" starts at {np.percentile(start, [0, 25, 50, 75, 100]).round(1)} us", flush=True)
 
 
 if __name__ == "__main__":
