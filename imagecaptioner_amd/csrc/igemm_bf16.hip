@@ -490,7 +490,7 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
           if (FULL || (m < p.M && nok)) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq = fmaf(v, v, ssq);
-            v = act_c<ACT>(v + bias);
+            if constexpr (ACT < 0) v = act_fn(v + bias, act); else v = act_c<ACT>(v + bias);
             long mr = m;
             if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {
               const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
@@ -517,12 +517,8 @@ __global__ __launch_bounds__(NT, 2) void igemm_bf16_kernel(const P p) {
   if (act == ICK_ACT_NONE) {
     if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{}, ActTag<ICK_ACT_NONE>{});
     else epilogue(std::false_type{}, ActTag<ICK_ACT_NONE>{});
-  } else if (act == ICK_ACT_RELU) {
-    epilogue(std::false_type{}, ActTag<ICK_ACT_RELU>{});
-  } else if (act == ICK_ACT_GELU) {
-    epilogue(std::false_type{}, ActTag<ICK_ACT_GELU>{});
   } else {
-    epilogue(std::false_type{}, ActTag<ICK_ACT_TANH>{});
+    epilogue(std::false_type{}, ActTag<-1>{});       // -1: the run-time form (rare on this path; saves three unrolled copies)
   }
 }
 

@@ -75,7 +75,7 @@ __device__ __attribute__((aligned(16))) float g_zero16[4];   // the zero page
 __device__ int g_stagger = 0;            // experiment: initial delay (units of 64 shader cycles) of the workgroups in odd wave slots
 #endif
 #if (ICK_EXP & 8)
-__device__ long long* g_dbg = nullptr;   // diagnostic builds: 8 words per workgroup (4 s_memtime stamps, HW_ID, XCC_ID)
+__device__ long long* g_dbg = nullptr;   // diagnostic builds: 16 words per workgroup (phase stamps, HW_ID, XCC_ID; 8..15: one k-tile's s_memtime stamps)
 #endif
 const bool g_no_vec_epilogue = [] { const char* e = getenv("ICK_NO_VEC_EPILOGUE"); return e && e[0] == '1'; }();   // A/B runs
 
@@ -96,16 +96,28 @@ __device__ __forceinline__ void glds16(const float* src, unsigned lds_wave_base)
 // footprint — the 128-row tiles otherwise leave 2-3 waves per SIMD to cover the per-k-tile barrier and the epilogues)
 // (tiles above 128 x 128 — the 256 x 256 tile of the native 16-bit variants — hold their two buffers in 128 KB of the CU's
 //  160 KB of LDS, one workgroup per CU, and keep their 128 accumulator registers per lane with the full 256-VGPR budget)
-template <int OP, int BM, int BN, int NBUF, int TERMS, int NW>
+// LW = LOADER waves (round 3).  In-kernel cycle stamps (tools/ablate/run_kloop.py stamps) showed where a k-tile's time goes
+// when a 128 x 128 workgroup has its CU to itself: 632 cycles waiting for its DMA, 584 at the barrier, 2248 ISSUING its eight
+// LDS-DMA pieces, 1464 + 3508 in the LDS reads and the 64 MFMAs (4096) — the vector-memory pipe of a CU takes in ~70 bytes per
+// cycle at best, an issuing wave simply blocks until its piece is accepted, and a blocked wave issues no MFMAs.  Moving the
+// pieces between the MFMA blocks (knob 2) changes nothing: the same wave still blocks.  With LW > 0 the workgroup carries LW
+// extra waves that do nothing but address arithmetic + DMA issue for ALL pieces of a k-tile and wait for them to land; the NW
+// compute waves never touch the vector-memory pipe inside the k-loop: barrier -> LDS reads -> MFMAs.  Every wave still meets
+// at ONE barrier per k-tile (tile kt landed / the buffer of tile kt-1 is free), roles are wave-uniform scalar branches.
+template <int OP, int BM, int BN, int NBUF, int TERMS, int NW, int LW = 0>
 // launch bounds: second argument = minimum waves per SIMD.  Two workgroups per CU for every tile up to 128 x 128: a 4-wave
 // workgroup then needs 2 (<= 256 VGPRs), an 8-wave one 4 (<= 128 VGPRs) — with 2 the eight-wave kernels silently fell to one
 // workgroup per CU once the epilogue grew past 128 registers (round 3, seen in the in-kernel stamps).
-__global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 2))) void igemm_glds_kernel(const P p) {
+// (loader variant: NW + LW = 8 waves with three buffers = one workgroup per CU, two waves per SIMD, 256 VGPRs.  A 4 + 2 wave
+//  form that keeps two workgroups per CU needs <= 168 VGPRs — three waves per SIMD — and spills 130-200 registers: not built)
+__global__ __launch_bounds__((NW + LW) * 64, (BM * BN > 128 * 128 ? 1 : (LW > 0 ? (NW + LW == 6 ? 3 : 2) : (NW == 8 ? 4 : 2))))
+void igemm_glds_kernel(const P p) {
   constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
-  constexpr int NT = NW * 64;
+  constexpr int NT = (NW + LW) * 64;
+  constexpr int DW = LW > 0 ? LW : NW;                    // waves that issue the DMA
   constexpr int WM = BM / (NW / 2), WN = BN / 2, TM = WM / 32, TN = WN / 32;
   static_assert(WM >= 32 && WN >= 32, "a wave owns at least one 32x32 MFMA tile");
-  constexpr int PA = BM / (8 * NW), PB = BN / (8 * NW);   // LDS-DMA instructions per thread per k-tile
+  constexpr int PA = BM / (8 * DW), PB = BN / (8 * DW);   // LDS-DMA instructions per issuing thread per k-tile
   constexpr int A_SZ = BM * BK, B_SZ = BN * BK, BUF = A_SZ + B_SZ;
   constexpr int A_TPK = BM / 4, B_TPK = BN / 4;        // lanes per k-row of an x-contiguous image
   constexpr int A_RPI = 64 / A_TPK, B_RPI = 64 / B_TPK;  // k-rows per DMA instruction (x-contiguous)
@@ -113,7 +125,11 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
 
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = LW > 0 ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);   // (scalar: the role branches must be s_cbranch)
+  const bool loader = LW > 0 && wave >= NW;          // this wave only feeds the LDS ring
+  const bool issuer = LW == 0 || loader;             // this wave issues DMA pieces
+  const int dw = LW > 0 ? (loader ? wave - NW : 0) : wave;   // index among the issuing waves
   const int wm = wave >> 1, wn = wave & 1;
   const int nwg = gridDim.x, q8 = nwg >> 3, r8 = nwg & 7, xcd = blockIdx.x & 7;   // XCD-aware tile order (igemm_f32.hip)
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
@@ -151,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
   const float* a_ptr[PA]; bool a_ok[PA]; int a_y[PA], a_x[PA], a_kq[PA];
 #pragma unroll
   for (int i = 0; i < PA; ++i) {
-    const int q = wave * PA + i;
+    const int q = dw * PA + i;
     if constexpr (AK) {
       const int row = q * 8 + (lane >> 3);
       a_kq[i] = (((lane & 7) ^ ((row >> 1) & 7)) << 2);
@@ -185,7 +201,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
   int b_r = 0, b_s = 0;
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
-    const int q = wave * PB + i;
+    const int q = dw * PB + i;
     if constexpr (BKc) {
       const int row = q * 8 + (lane >> 3);
       b_kq[i] = (((lane & 7) ^ ((row >> 1) & 7)) << 2);
@@ -231,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
     const int k0 = t.k0;
     if (q < PA) {
       const int i = q;
-      const unsigned dst = lds_base + 4u * (buf * BUF + wave * (PA * 256)) + i * 1024;       // LDS byte address (wave-uniform)
+      const unsigned dst = lds_base + 4u * (buf * BUF + dw * (PA * 256)) + i * 1024;       // LDS byte address (wave-uniform)
       bool ok; const float* src;
       if constexpr (OP == ICK_OP_NT || OP == ICK_OP_NN) {
         ok = a_ok[i] && (k0 + a_kq[i] < kend); src = a_ptr[i] + k0;
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
       glds16((ok && t.valid) ? src : zpage, dst);
     } else {
       const int i = q - PA;
-      const unsigned dst = lds_base + 4u * (buf * BUF + A_SZ + wave * (PB * 256)) + i * 1024;
+      const unsigned dst = lds_base + 4u * (buf * BUF + A_SZ + dw * (PB * 256)) + i * 1024;
       bool ok; const float* src;
       if constexpr (BKc) {
         ok = b_ok[i] && (k0 + b_kq[i] < kend); src = b_ptr[i] + k0;
@@ -358,16 +374,25 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
       for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   int chain = 0;
 
-  constexpr bool IL = (ICK_EXP & 2) != 0 && TERMS == 0;   // piecewise DMA schedule (knob 2)
+  constexpr bool IL = (ICK_EXP & 2) != 0 && TERMS == 0 && LW == 0;   // piecewise DMA schedule (knob 2)
   auto stamp = [&](int slot, bool on) {
 #if (ICK_EXP & 8)
     if (on && g_dbg) {
       const long long tm = __builtin_amdgcn_s_memrealtime();   // 100 MHz wall clock
       if (tid == 0) {
-        long long* d = g_dbg + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 8;
+        long long* d = g_dbg + ((long)blockIdx.z * gridDim.x + blockIdx.x) * 16;
         d[slot] = tm;
         if (slot == 0) { d[6] = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 4); d[7] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 20); }
       }
+    }
+#endif
+  };
+  // cycle stamps inside ONE k-tile (the third), wave 0 of every workgroup: where a k-tile's non-MFMA time goes
+  auto kstamp = [&](int slot, int kt) {
+#if (ICK_EXP & 64)
+    if (kt == 2 && g_dbg) {
+      const long long tm = __builtin_amdgcn_s_memtime();
+      if (tid == 0) g_dbg[((long)blockIdx.z * gridDim.x + blockIdx.x) * 16 + 8 + slot] = tm;
     }
 #endif
   };
@@ -395,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
 #pragma unroll
       for (int q = 0; q < NP; ++q) issue_piece(t1, q, 1);
     }
-  } else {
+  } else if (issuer) {
     if (nkt > 0) issue(0, 0);
     if (NBUF == 3 && nkt > 1) issue(1, 1);
   }
@@ -403,21 +428,28 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
   for (int kt = 0; kt < nkt; ++kt) {
     // my DMA of tile kt has landed; after the barrier so has everybody's, and everybody is done reading the buffer
     // that the next DMA overwrites
-    if (NBUF == 3 && (IL || kt + 1 < nkt)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    kstamp(0, kt);
+    if (issuer) {
+      if (NBUF == 3 && (IL || kt + 1 < nkt)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    kstamp(1, kt);
     __syncthreads();
+    kstamp(2, kt);
     stamp(1, kt == 0);
     const int nbuf = cb == 0 ? NBUF - 1 : cb - 1;   // the buffer the next DMA fills
     KTile nxt_t = ktile(kt + NBUF - 1, kt + NBUF - 1 < nkt);
     if constexpr (!IL) {
 #if ICK_ABL == 3
-      if (kt + NBUF - 1 < nkt && p.alpha == 12345.f) issue(kt + NBUF - 1, nbuf);
+      if (issuer && kt + NBUF - 1 < nkt && p.alpha == 12345.f) issue(kt + NBUF - 1, nbuf);
 #else
-      if (kt + NBUF - 1 < nkt) issue(kt + NBUF - 1, nbuf);
+      if (issuer && kt + NBUF - 1 < nkt) issue(kt + NBUF - 1, nbuf);
 #endif
     }
+    kstamp(3, kt);
     const float* Ab = lds + cb * BUF;
     cb = cb + 1 == NBUF ? 0 : cb + 1;
+    if (LW > 0 && loader) continue;                  // a loader's k-tile ends here: on to waiting for the next tile's pieces
     const float* Bb = Ab + A_SZ;
     if constexpr (TERMS == 0 || TERMS >= 5) {
       // fragment registers: two sets (the next group's reads fly under this group's MFMAs); ONE set for the 256 x 256 tile,
@@ -467,6 +499,8 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
           }
         if constexpr ((ICK_EXP & 4) != 0) if (j == BK / 8 - 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        if (j == 0) kstamp(4, kt);
+        if (j == BK / 8 - 1) kstamp(5, kt);
         if (FB == 1 && j + 1 < BK / 8) {
   #pragma unroll
           for (int i = 0; i < TM; ++i) av[0][i] = frag_a(Ab, j + 1, i);
@@ -559,7 +593,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
     for (int sl = 0; sl < SLABS; ++sl) {
     const int srow0 = sl * SROWS;
     __syncthreads();                       // every wave is out of the k-loop / the previous slab is stored: the LDS buffers become the C slab [SROWS][BN]
-    if (SLABS == 1 || (wm * WM) / SROWS == sl) {
+    if (!loader && (SLABS == 1 || (wm * WM) / SROWS == sl)) {
     // registers -> LDS, one specialised copy per activation (igemm_params.h act_dispatch); the statistics only where asked for
     act_dispatch(post ? ICK_ACT_NONE : act, [&](auto act_tag) {
     constexpr int ACT = decltype(act_tag)::value;
@@ -650,7 +684,7 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
           if ((FULL || (m < p.M && nok)) && (ICK_ABL < 2 || ICK_ABL >= 4 || alpha == 12345.f)) {
             float v = acc[i][j][r] * alpha;
             ssum += v; ssq = fmaf(v, v, ssq);
-            v = act_c<ACT>(v + bias);
+            if constexpr (ACT < 0) v = act_fn(v + bias, act); else v = act_c<ACT>(v + bias);
             long mr = m;
             if constexpr (OP == ICK_OP_CONV_DGRAD_S2) {   // class row -> pixel row of the full-resolution dX
               const int w2 = p.W >> 1; const int hw = (p.H >> 1) * w2; const int b = m / hw; const int q = m - b * hw;
@@ -680,22 +714,19 @@ __global__ __launch_bounds__(NW * 64, (BM * BN > 128 * 128 ? 1 : (NW == 8 ? 4 : 
   };
   // (interior tiles check-free; activations other than none / ReLU reach this dword path only with an unaligned C: they share
   //  the boundary-checked copy)
+  if (loader) return;
   if (act == ICK_ACT_NONE) {
     if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{}, ActTag<ICK_ACT_NONE>{});
     else epilogue(std::false_type{}, ActTag<ICK_ACT_NONE>{});
-  } else if (act == ICK_ACT_RELU) {
-    epilogue(std::false_type{}, ActTag<ICK_ACT_RELU>{});
-  } else if (act == ICK_ACT_GELU) {
-    epilogue(std::false_type{}, ActTag<ICK_ACT_GELU>{});
   } else {
-    epilogue(std::false_type{}, ActTag<ICK_ACT_TANH>{});
+    epilogue(std::false_type{}, ActTag<-1>{});       // -1: the run-time form (one more copy would cost registers for a rare path)
   }
   stamp(3, true);
 }
 
 // rows [m_begin, m_end) of the problem (m_end <= 0: all of M).  A launch over a row range is what the M-split dispatch
 // uses: bounds are checked against p.M = m_end, addresses are formed from the global row index.
-template <int OP, int BM, int BN, int NBUF, int TERMS, int NW = 4>
+template <int OP, int BM, int BN, int NBUF, int TERMS, int NW = 4, int LW = 0>
 int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) {
   P p = p0;
   if (m_end <= 0 || m_end > p.M) m_end = p.M;
@@ -710,7 +741,7 @@ int launch(const P& p0, int nz, hipStream_t st, int m_begin = 0, int m_end = 0) 
   if ((p.c16 || p.r16) && !((TERMS != 0 && TERMS != 3) && p.ep_vec && p.splitk == 1))
     return ick::fail(-1, "igemm: a 16-bit C / residual needs a 16-bit MFMA variant of the LDS-DMA kernel, N %% 4, ldc %% 4, ldr %% 4 and no split-K");
   dim3 grid(p.tiles_n * ((p.M - m_begin + BM - 1) / BM), 1, nz);
-  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW>), grid, dim3(NW * 64), 0, st, p);
+  ICK_LAUNCH((igemm_glds_kernel<OP, BM, BN, NBUF, TERMS, NW, LW>), grid, dim3((NW + LW) * 64), 0, st, p);
   return ick::launch_status("igemm_glds");
 }
 
@@ -728,6 +759,9 @@ int launch_tile(const P& p, int nz, hipStream_t st, int tile, int m_begin = 0, i
     case 65: return launch<OP, 128, 128, 2, TERMS, 8>(p, nz, st, m_begin, m_end);     // +64: eight waves per workgroup
     case 67: return launch<OP, 128, 64, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
     case 83: return launch<OP, 128, 64, 3, TERMS, 8>(p, nz, st, m_begin, m_end);
+    case 129:     // +128: loader waves.  129 = 4 compute + 4 loader waves, three buffers: ONE workgroup per CU (long-K shapes)
+      if constexpr (TERMS == 0 && (OP == ICK_OP_NT || OP == ICK_OP_CONV_FWD)) return launch<OP, 128, 128, 3, TERMS, 4, 4>(p, nz, st, m_begin, m_end);
+      else return launch<OP, 128, 128, 2, TERMS>(p, nz, st, m_begin, m_end);
     case 69:      // 256 x 256 x (64 halves), eight waves as 4 x 2 (64 x 128 per wave): large plain GEMMs on native 16-bit operands
       if constexpr (TERMS >= 5 && OP == ICK_OP_NT) return launch<OP, 256, 256, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
       else return launch<OP, 128, 128, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
@@ -757,8 +791,8 @@ template <int OP, int TERMS>
 int dispatch_tile(const P& p, int nz, hipStream_t st, int tile) {
   static const int bm[4] = {128, 64, 128, 64}, bn[4] = {128, 64, 64, 128};
   static const double eff[4] = {1.00, 0.85, 0.93, 0.93};   // relative efficiency of the tile shape
-  bool split = (tile & 32) != 0;
-  tile &= 64 | 31;
+  bool split = (tile & 32) != 0 && !(tile & 128);
+  tile &= 128 | 64 | 31;
   if ((tile & 31) == 0) {
     double best = 1e300;
     auto cost_of = [&](int t, long rows) {                   // busiest CU's share of tile area / efficiency

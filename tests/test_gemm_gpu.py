@@ -161,7 +161,7 @@ def test_conv_stem_c4(ops):
     assert torch.equal(mp.permute(0, 3, 1, 2).cpu(), F.max_pool2d(y.permute(0, 3, 1, 2).cpu(), 3, 2, 1))
 
 
-@pytest.mark.parametrize("tile", [34, 35, 36, 50, 0, 65, 67, 83, 65 + 32])
+@pytest.mark.parametrize("tile", [34, 35, 36, 50, 0, 65, 67, 83, 65 + 32, 129])
 def test_msplit_dispatch_linear_and_conv_vs_fp64(tile):
     """IckGemm.tile +32: rows that fill whole rounds of the chip run on 128x128 workgroups, the remaining rows in a second
     launch with a smaller tile (tile 0 lets the library's cost model decide).  Both launches must cover every row exactly
@@ -234,10 +234,11 @@ def test_full_size_step_shapes_with_their_tuned_tiles_vs_fp64():
     assert rel_err(yb, xb.double() @ wb.double().T + bb.double() + rb.double()) < 2e-5
 
 
-@pytest.mark.parametrize("tile", [65, 67, 83])
+@pytest.mark.parametrize("tile", [65, 67, 83, 129])
 def test_eight_wave_tiles_all_ops_vs_fp64(tile):
     """IckGemm.tile +64: the 128-row tiles with eight waves per workgroup (4 x 2 wave grid) — every operand-fetch pattern of
-    the LDS-DMA kernel (k-contiguous / x-contiguous A and B, conv gathers, stride-2 parity classes) against float64."""
+    the LDS-DMA kernel (k-contiguous / x-contiguous A and B, conv gathers, stride-2 parity classes) against float64.
+    129: four compute + four loader waves, three buffers (NT and CONV_FWD; the other ops fall back to the 128 x 128 tile)."""
     from imagecaptioner_amd import ops as o
     o._FORCE_TILE[0] = tile
     try:

@@ -35,7 +35,7 @@ CASES = [("NT 4096^3", 0, 4096, 4096, 4096, None, 0), ("fc1 12608x1536x384 gelu"
          ("conv1x1 14x14 256->1024", 3, B * 14 * 14, 1024, 256, (B, 14, 14, 256, 14, 14, 1024, 1, 1, 1, 0), 0),
          ("conv3x3 28x28 128->128", 3, B * 28 * 28, 128, 1152, (B, 28, 28, 128, 28, 28, 128, 3, 3, 1, 1), 0),
          ("conv1x1 56x56 64->256", 3, B * 56 * 56, 256, 64, (B, 56, 56, 64, 56, 56, 256, 1, 1, 1, 0), 0)]
-TILES = [1, 65, 3, 4, 2, 19]
+TILES = [1, 65, 129, 4, 2]
 
 
 def desc(torch, IckGemm, bufs, op, M, N, K, conv, act, tile, out):
@@ -114,14 +114,14 @@ def main():
               assert L.ick_exp_set_stagger(int(stag_us * 2100 / 64)) == 0
               print(f"==== stagger {stag_us} us", flush=True)
           for name, op, M, N, K, conv, act in CASES[:3] + CASES[5:6]:
-            for tile in (1, 65):
-                  dbg = torch.zeros(8 * 65536, dtype=torch.int64, device="cuda")
+            for tile in (1, 65, 129):
+                  dbg = torch.zeros(16 * 65536, dtype=torch.int64, device="cuda")
                   assert L.ick_exp_set_dbg(ctypes.c_void_p(dbg.data_ptr())) == 0
                   d = desc(torch, IckGemm, bufs, op, M, N, K, conv, act, tile, y)
                   for _ in range(3):
                       L.ick_gemm_f32(ctypes.byref(d), st)
                   torch.cuda.synchronize()
-                  a = dbg.cpu().numpy().reshape(-1, 8)
+                  a = dbg.cpu().numpy().reshape(-1, 16)
                   a = a[a[:, 0] != 0]
                   t0 = a[:, 0].min()
                   clk = 100e6                                           # s_memrealtime: 100 MHz
@@ -133,6 +133,11 @@ def main():
                       print(f"      epilogue split (thread 0): barrier + registers->LDS {np.median(e1):.2f} (p90 {np.percentile(e1, 90):.2f})  "
                             f"second barrier {np.median(e2):.2f} (p90 {np.percentile(e2, 90):.2f})  LDS->global stores issued "
                             f"{np.median(e3):.2f} (p90 {np.percentile(e3, 90):.2f}) us", flush=True)
+                  if (a[:, 13] != 0).any():
+                      kk = a[a[:, 13] != 0]
+                      seg = [np.median(kk[:, 9 + i] - kk[:, 8 + i]) for i in range(5)]
+                      print("      one k-tile, wave 0, shader cycles: wait own DMA %d | barrier %d | DMA issue %d | LDS reads + first MFMA group "
+                            "%d | remaining MFMA groups %d  (sum %d; 64 MFMAs = 4096 at one wave per SIMD)" % (*seg, sum(seg)), flush=True)
                   hw, xcc = a[:, 6], a[:, 7]
                   cu = ((xcc & 15) << 8) | (((hw >> 13) & 7) << 5) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15)
                   print(f"EXP {n} {name} tile {tile}: {len(a)} workgroups on {len(np.unique(cu))} CUs, span {end.max():.1f} us; per-workgroup "

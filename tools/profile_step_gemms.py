@@ -71,8 +71,8 @@ out = torch.empty(1 << 27, device="cuda")
 stat = torch.zeros(2, 8 * 4096, dtype=torch.float64, device="cuda")
 rows = []
 TN_ = ["model", "128x128", "64x64", "128x64", "64x128", "3b64x64", "3b128x64", "3b64x128", "r128x128", "r64x64", "r128x64", "r64x128",
-       "s+64x64", "s+128x64", "s+64x128", "s+3b64x64", "8w128x128", "8w128x64", "8w3b128x64"]
-TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260, 34, 35, 36, 50, 65, 67, 83]   # +16: three LDS buffers; +32: M-split (128x128 body + that tail tile); +256: the register-staged kernel
+       "s+64x64", "s+128x64", "s+64x128", "s+3b64x64", "8w128x128", "8w128x64", "8w3b128x64", "ld128x128"]
+TILES = [0, 1, 2, 3, 4, 18, 19, 20, 257, 258, 259, 260, 34, 35, 36, 50, 65, 67, 83, 129]   # +16: three LDS buffers; +32: M-split (128x128 body + that tail tile); +256: the register-staged kernel; 129: 4 compute + 4 loader waves, three buffers
 if PREC != "f32":
     ops.set_gemm_precision(PREC)
 
@@ -105,6 +105,9 @@ for r, n in cnt.items():
     ts = []
     kc = op in (0, 3)                                        # NT / CONV_FWD: the LDS-DMA kernel exists for 16-bit operands
     for tile in TILES:
+        if tile == 129 and (PREC != "f32" or op not in (0, 3)):
+            ts.append(float("inf"))          # loader-wave variant: exact-fp32 NT / CONV_FWD only
+            continue
         if H16 is not None and ((not kc and (tile > 4)) or (tile & 32)):
             ts.append(float("inf"))          # register-staged kernel only: the four plain tiles
             continue
