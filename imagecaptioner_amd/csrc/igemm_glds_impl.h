@@ -199,6 +199,11 @@ void igemm_glds_kernel(const P p) {
   }
   const float* b_ptr[PB]; bool b_ok[PB]; int b_y[PB], b_kq[PB];
   int b_r = 0, b_s = 0;
+  // weight gradient: the output pixel (image, row, column) behind each piece's k index, kept INCREMENTALLY — a k-tile advances
+  // every lane's pixel by BK, so the two integer divisions per piece per k-tile of the direct form (~50 VALU instructions
+  // each) become a handful of adds and compares.  Pieces are issued in k-tile order, which is what makes this valid.
+  int w_img[PB], w_oy[PB], w_ox[PB];
+  const int w_q = OP == ICK_OP_CONV_WGRAD ? BK / max(p.Wo, 1) : 0, w_r = OP == ICK_OP_CONV_WGRAD ? BK - w_q * p.Wo : 0;
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int q = dw * PB + i;
@@ -216,6 +221,9 @@ void igemm_glds_kernel(const P p) {
         const int tap = n / p.Cin; const int ci = n - tap * p.Cin;
         b_r = tap / p.S; b_s = tap - b_r * p.S;
         b_ptr[i] = Bg + ci;
+        const int hw = p.Ho * p.Wo;
+        const int k = kbeg + b_y[i];
+        w_img[i] = k / hw; const int rem = k - w_img[i] * hw; w_oy[i] = rem / p.Wo; w_ox[i] = rem - w_oy[i] * p.Wo;
       } else {
         b_ptr[i] = Bg + n;
       }
@@ -286,12 +294,13 @@ void igemm_glds_kernel(const P p) {
         const int co = t.c0 + b_y[i];
         ok = b_ok[i] && (k0 + b_y[i] < kend); src = b_ptr[i] + ((long)co * p.R * p.S + t.tap) * p.Cin;
       } else if constexpr (OP == ICK_OP_CONV_WGRAD) {
-        const int hw = p.Ho * p.Wo;
         const int k = k0 + b_y[i];
-        const int b = k / hw; const int rem = k - b * hw; const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        const int iy = oy * p.stride - p.pad + b_r, ix = ox * p.stride - p.pad + b_s;
+        const int iy = w_oy[i] * p.stride - p.pad + b_r, ix = w_ox[i] * p.stride - p.pad + b_s;
         ok = b_ok[i] && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        src = b_ptr[i] + (((long)b * p.H + iy) * p.W + ix) * p.Cin;
+        src = b_ptr[i] + (((long)w_img[i] * p.H + iy) * p.W + ix) * p.Cin;
+        w_ox[i] += w_r; w_oy[i] += w_q;                     // the same piece of the NEXT k-tile: BK pixels on
+        if (w_ox[i] >= p.Wo) { w_ox[i] -= p.Wo; ++w_oy[i]; }
+        while (w_oy[i] >= p.Ho) { w_oy[i] -= p.Ho; ++w_img[i]; }
       } else {  // B [K][N]
         const int k = k0 + b_y[i];
         ok = b_ok[i] && k < kend; src = b_ptr[i] + (long)k * p.ldb;

@@ -481,6 +481,9 @@ def conv_weight_dgrad_layout(w: torch.Tensor) -> torch.Tensor:
     return wt
 
 
+_WGRAD_1X1_AS_TN = [os.environ.get("ICK_WGRAD_1X1_AS_TN", "1") != "0"]     # A/B switch
+
+
 def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int, pad: int, splitk: int = 0) -> None:
     """dw (Cout,R,S,Cin) += sum over output pixels of dy (x) gathered x (accumulates, fp32 atomics when split); dw is fp32,
     dy and x fp32 or both bf16 / fp16 (native 16-bit operands)."""
@@ -491,6 +494,17 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int,
     io = dict(h16=_h16(dy), default_tile=3) if _h16(dy) is not None else {}      # 128x64: best or within 3 % on every shape measured
     K = Nb * Ho * Wo
     N = R * S * Cin
+    if R == 1 and S == 1 and stride == 1 and pad == 0 and not io and _WGRAD_1X1_AS_TN[0]:
+        # a 1x1 / stride-1 convolution's im2col is the identity: dW[co][ci] = sum_pix dY[pix][co] X[pix][ci] is a plain TN GEMM,
+        # which the LDS-DMA kernel runs 10-30 % faster than the register-staged CONV_WGRAD gather kernel (tools/bench_wgrad_tn.py,
+        # profiles/r03_wgrad_1x1_as_tn.log: 1024x256x12544 68.7 us against 84; 128x512x50176 74 against 106).  ~800 pixels per
+        # split (8 <= splits <= 48); the tile comes from the tuned table (128x64 otherwise)
+        sk = splitk if splitk > 0 else (max(8, min(48, K // 784)) if K >= 3136 else max(1, K // 392))
+        if sk > 1:
+            gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, Cin, K, Cout, Cin, Cin, splitk=sk, default_tile=3)
+        else:
+            gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, Cin, K, Cout, Cin, Cin, accumulate=True, default_tile=3)
+        return
     if splitk <= 0 and io:
         # native 16-bit operands (measured, tools/bench_wgrad16.py): ~784 pixels per split is the sweet spot on every layer3 /
         # layer4 shape (1024x256x12544: 40 us at 16 splits against 56 at 48; 2048x512x3136: 39 us at 4 against 54 at 12),

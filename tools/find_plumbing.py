@@ -26,10 +26,10 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
 WATCH = ("aten::copy_", "aten::fill_", "aten::zero_", "aten::add", "aten::add_", "aten::mul", "aten::mul_", "aten::cat", "aten::clone",
          "aten::contiguous", "aten::_to_copy", "aten::sum", "aten::stack", "aten::index_select", "aten::zeros", "aten::div", "aten::sub")
 agg = collections.Counter()
-for ev in prof.events():
-    if ev.name in WATCH and ev.device_time_total > 0 and ev.stack:
-        frames = [f for f in ev.stack if "imagecaptioner_amd" in f]
-        where = " <- ".join(fr.split("imagecaptioner_amd/")[-1] for fr in frames[:2]) if frames else (ev.stack[0] if ev.stack else "?")
-        agg[(ev.name, where)] += 1
+for ev in prof.key_averages(group_by_stack_n=12):
+    if ev.key in WATCH:
+        frames = [f for f in (ev.stack or []) if "imagecaptioner_amd" in f]
+        where = " <- ".join(fr.split("imagecaptioner_amd/")[-1].split(" ")[0] for fr in frames[:2]) if frames else ((ev.stack or ["?"])[0])
+        agg[(ev.key, where)] += ev.count
 for (name, where), n in sorted(agg.items(), key=lambda kv: -kv[1]):
     print(f"{n:4d}  {name:18s} {where}")

@@ -1,0 +1,16 @@
+set -x
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+python -m pytest $R/tests/test_amp_yardstick_gpu.py -q > $R/gpurun_out/test_amp2.log 2>&1
+python3 $R/tools/find_plumbing.py > $R/gpurun_out/plumbing.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_step -o step -- python3 $R/bench.py --steps 10 --warmup 5 --no-extras --no-cpu-baseline > $R/gpurun_out/prof_step.json 2> $R/gpurun_out/prof_step.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $R/gpurun_out/pmc_step -o s -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_step.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_fetch -o f -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_write -o w -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2> $R/gpurun_out/pmc_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_dom -o dom -- python3 $R/bench.py --dominant-kernel-only > $R/gpurun_out/prof_dom.json 2> $R/gpurun_out/prof_dom.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 --kernel-trace --output-format csv -d $R/gpurun_out/pmc_dom -o d -- python3 $R/bench.py --dominant-kernel-only > /dev/null 2> $R/gpurun_out/pmc_dom.err
+cd $R
+python tools/step_pmc.py gpurun_out/pmc_step > gpurun_out/r03_step_pmc.json
+python tools/measure_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > gpurun_out/r03_traffic.json
+ls -la gpurun_out/prof_step gpurun_out/pmc_step | head -20
+tail -n 4 gpurun_out/test_amp2.log
