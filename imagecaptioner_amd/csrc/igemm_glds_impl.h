@@ -66,8 +66,10 @@ constexpr int kCUs = 256;            // MI355X
 //      one burst behind the barrier (the burst holds the wave's instruction stream for ~50 cycles per piece with the matrix pipe idle)
 //   4  s_setprio 1 across the MFMA blocks (the co-resident workgroup's address arithmetic yields to a wave that has MFMAs to issue)
 //   8  s_memtime stamps per workgroup into g_dbg (diagnostic builds only)
+// libick.so is built with knobs 1 + 4 (measured +1..3 % on the step's shapes, +5 % at 4096^3; profiles/r03_kloop_knobs.log);
+// 2 / 8 / 32 / 64 exist for tools/ablate only.
 #ifndef ICK_EXP
-#define ICK_EXP 0
+#define ICK_EXP 5
 #endif
 
 __device__ __attribute__((aligned(16))) float g_zero16[4];   // the zero page
@@ -108,9 +110,11 @@ template <int OP, int BM, int BN, int NBUF, int TERMS, int NW, int LW = 0>
 // launch bounds: second argument = minimum waves per SIMD.  Two workgroups per CU for every tile up to 128 x 128: a 4-wave
 // workgroup then needs 2 (<= 256 VGPRs), an 8-wave one 4 (<= 128 VGPRs) — with 2 the eight-wave kernels silently fell to one
 // workgroup per CU once the epilogue grew past 128 registers (round 3, seen in the in-kernel stamps).
-// (loader variant: NW + LW = 8 waves with three buffers = one workgroup per CU, two waves per SIMD, 256 VGPRs.  A 4 + 2 wave
-//  form that keeps two workgroups per CU needs <= 168 VGPRs — three waves per SIMD — and spills 130-200 registers: not built)
-__global__ __launch_bounds__((NW + LW) * 64, (BM * BN > 128 * 128 ? 1 : (LW > 0 ? (NW + LW == 6 ? 3 : 2) : (NW == 8 ? 4 : 2))))
+// (loader variant: NW + LW = 8 waves with three buffers = one workgroup per CU, two waves per SIMD, 256 VGPRs.  Forms that
+//  keep TWO workgroups per CU were tried and dropped: 4 + 2 waves on 128 x 128 needs <= 168 VGPRs and spills 130-200
+//  registers; 4 + 4 waves on 128 x 64 / 64 x 128 (<= 128 VGPRs, no spills, bit-identical results) ran 5-15 % SLOWER than the
+//  plain 4-wave tiles on every ViT shape — profiles/r03_kloop_knobs.log, last block)
+__global__ __launch_bounds__((NW + LW) * 64, (BM * BN > 128 * 128 ? 1 : (LW > 0 ? (NBUF == 2 ? 4 : 2) : (NW == 8 ? 4 : 2))))
 void igemm_glds_kernel(const P p) {
   constexpr bool AK = a_kcontig(OP), BKc = b_kcontig(OP);
   constexpr int NT = (NW + LW) * 64;

@@ -256,89 +256,123 @@ class CompactCNNEncoder(nn.Module):
 
 
 class CompactDecoderFn(Function):
-    """teacher-forced decode of all T steps + hand-written BPTT (reference loop: student_model_compact.py:163-190)."""
+    """teacher-forced decode of all T steps + hand-written BPTT (reference loop: student_model_compact.py:163-190), any number
+    of LSTM layers, optional caller-supplied initial state (h0, c0), each (layers, B, H) (reference :140,:155-156): the
+    attention query is the TOP layer's state of the previous step (`hidden[0][-1]`, :172)."""
 
     @staticmethod
-    def forward(ctx, feats, captions, dec: "CompactLSTMDecoder", *params):
+    def forward(ctx, feats, captions, dec: "CompactLSTMDecoder", h0, c0, *params):
         feats, captions = hnn._c(feats), hnn._c(captions)
         T, B = captions.shape
         _, P, E = feats.shape
-        H, V = dec.hidden_size, dec.vocab_size
+        H, V, NL = dec.hidden_size, dec.vocab_size, dec.num_layers
         dev = feats.device
-        wi, wh, bi, bh = dec.lstm.layer(0)
+        if h0 is not None:
+            h0, c0 = hnn._c(h0.detach()), hnn._c(c0.detach())
         Wa, ba = dec.attention.weight, dec.attention.bias
         emb = ops.embedding_fwd(captions, dec.embedding.weight)            # (T,B,E)
         keep = any(ctx.needs_input_grad)
-        Hall, Call = ops.empty(T, B, H, device=dev), ops.empty(T, B, H, device=dev)
-        Gates = ops.empty(T, B, 4 * H, device=dev) if keep else None
+        Hall, Call = ops.empty(NL, T, B, H, device=dev), ops.empty(NL, T, B, H, device=dev)
+        Gates = ops.empty(NL, T, B, 4 * H, device=dev) if keep else None
         HP = ops.empty(T, B, E, device=dev)
         attw, X = ops.empty(T, B, P, device=dev), ops.empty(T, B, E, device=dev)
         zero_h = ops.zeros(B, H, device=dev)
+        hp = lambda l, t: Hall[l, t - 1] if t > 0 else (h0[l] if h0 is not None else None)
+        cp = lambda l, t: Call[l, t - 1] if t > 0 else (c0[l] if c0 is not None else None)
         for t in range(T):
-            h_prev = Hall[t - 1] if t > 0 else zero_h
-            ops.gemm_nt(h_prev, Wa.data_ptr(), E, H, H, HP[t], bias=ba)
+            h_top = hp(NL - 1, t)
+            ops.gemm_nt(h_top if h_top is not None else zero_h, Wa.data_ptr(), E, H, H, HP[t], bias=ba)
             ops.dot_attn_fwd(HP[t], feats, emb[t], attw[t], X[t])
-            ops.lstm_layer_fwd(X[t], Hall[t - 1] if t > 0 else None, wi, wh, bi, bh, Call[t - 1] if t > 0 else None,
-                               Gates[t] if keep else None, Call[t], Hall[t])
+            inp = X[t]
+            for l in range(NL):
+                wi, wh, bi, bh = dec.lstm.layer(l)
+                ops.lstm_layer_fwd(inp, hp(l, t), wi, wh, bi, bh, cp(l, t), Gates[l, t] if keep else None, Call[l, t], Hall[l, t])
+                inp = Hall[l, t]
         Wo, bo = dec.output_projection.weight, dec.output_projection.bias
-        logits = ops.linear_fwd(Hall.view(T * B, H), Wo, bo).view(T, B, V)
+        Htop = Hall[NL - 1]
+        logits = ops.linear_fwd(Htop.view(T * B, H), Wo, bo).view(T, B, V)
         if keep:
-            ctx.dec, ctx.dims = dec, (T, B, P, E, H, V)
-            ctx.saved = dict(feats=feats, captions=captions, Hall=Hall, Call=Call, Gates=Gates, HP=HP, attw=attw, X=X)
+            ctx.dec, ctx.dims = dec, (T, B, P, E, H, V, NL)
+            ctx.saved = dict(feats=feats, captions=captions, Hall=Hall, Call=Call, Gates=Gates, HP=HP, attw=attw, X=X, h0=h0, c0=c0)
         ctx.mark_non_differentiable(attw)
-        return logits, Hall, attw
+        return logits, Htop, attw
 
     @staticmethod
     def backward(ctx, dlogits, dH_ext, _dattw):
         dec, s = ctx.dec, ctx.saved
-        T, B, P, E, H, V = ctx.dims
+        T, B, P, E, H, V, NL = ctx.dims
         dev = s["feats"].device
         gb = hnn.grad_buf
-        wi, wh, bi, bh = dec.lstm.layer(0)
         Wa, Wo = dec.attention.weight, dec.output_projection.weight
-        Hall, Call, Gates = s["Hall"], s["Call"], s["Gates"]
+        Hall, Call, Gates, h0, c0 = s["Hall"], s["Call"], s["Gates"], s["h0"], s["c0"]
+        Htop = Hall[NL - 1]
         if dlogits is not None:
             dl = hnn._c(dlogits).view(T * B, V)
             dHs = ops.empty(T, B, H, device=dev)
             ops.gemm_nn(dl, Wo.data_ptr(), V, H, H, dHs, residual=hnn._c(dH_ext) if dH_ext is not None else None)
             if Wo.requires_grad:
-                ops.linear_bwd_weight(dl, Hall.view(T * B, H), gb(Wo))
+                ops.linear_bwd_weight(dl, Htop.view(T * B, H), gb(Wo))
                 ops.colsum_into(dl, gb(dec.output_projection.bias))
         else:
             dHs = hnn._c(dH_ext) if dH_ext is not None else ops.zeros(T, B, H, device=dev)
-        DG = ops.empty(T, B, 4 * H, device=dev)
+        DG = ops.empty(NL, T, B, 4 * H, device=dev)
         dX = ops.empty(T, B, E, device=dev)
         dHP = ops.empty(T, B, E, device=dev)
         dfeats = ops.zeros(B, P, E, device=dev)
-        carry_c = ops.zeros(B, H, device=dev)
-        carry_h = ops.zeros(T, B, H, device=dev)            # carry_h[t]: dL/dh(t) arriving from step t+1 (split-K arena)
+        carry_c = [ops.zeros(B, H, device=dev) for _ in range(NL)]
+        carry_h = ops.zeros(NL, T, B, H, device=dev)        # carry_h[l, t]: dL/dh_l(t) arriving from step t+1 (split-K arena)
+        d_inp = ops.zeros(NL, B, H, device=dev) if NL > 1 else None     # gradient into layer l's input at the current step
+        want_state = h0 is not None and (ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        dh0 = ops.zeros(NL, B, H, device=dev) if want_state else None
         for t in range(T - 1, -1, -1):
-            ops.lstm_cell_bwd(dHs[t], carry_h[t] if t < T - 1 else None, carry_c if t < T - 1 else None, Gates[t], Call[t],
-                              Call[t - 1] if t > 0 else None, DG[t], carry_c)
-            ops.gemm_nn(DG[t], wi.data_ptr(), 4 * H, E, E, dX[t])                       # d(emb + ctx)
+            for l in range(NL - 1, -1, -1):
+                wi, wh, _, _ = dec.lstm.layer(l)
+                dh_a = dHs[t] if l == NL - 1 else d_inp[l + 1]
+                c_prev = Call[l, t - 1] if t > 0 else (c0[l] if c0 is not None else None)
+                ops.lstm_cell_bwd(dh_a, carry_h[l, t] if t < T - 1 else None, carry_c[l] if t < T - 1 else None, Gates[l, t],
+                                  Call[l, t], c_prev, DG[l, t], carry_c[l])
+                if l > 0:
+                    ops.gemm_nn(DG[l, t], wi.data_ptr(), 4 * H, H, H, d_inp[l])
+                else:
+                    ops.gemm_nn(DG[0, t], wi.data_ptr(), 4 * H, E, E, dX[t])              # d(emb + ctx)
+                if t > 0:
+                    ops.gemm_nn(DG[l, t], wh.data_ptr(), 4 * H, H, H, carry_h[l, t - 1], zeroed=True)
+                elif want_state:
+                    ops.gemm_nn(DG[l, 0], wh.data_ptr(), 4 * H, H, H, dh0[l], zeroed=True)
             ops.dot_attn_bwd(dX[t], s["attw"][t], s["HP"][t], s["feats"], dfeats, dHP[t])
             if t > 0:
-                ops.gemm_nn(DG[t], wh.data_ptr(), 4 * H, H, H, carry_h[t - 1], zeroed=True)
-                ops.gemm_nn(dHP[t], Wa.data_ptr(), E, H, H, carry_h[t - 1], accumulate=True)
-        DG2 = DG.view(T * B, 4 * H)
-        if wi.requires_grad:
-            ops.gemm_tn_acc(DG2, s["X"].view(T * B, E), gb(wi).data_ptr(), 4 * H, E, E)
+                ops.gemm_nn(dHP[t], Wa.data_ptr(), E, H, H, carry_h[NL - 1, t - 1], accumulate=True)
+            elif want_state:
+                ops.gemm_nn(dHP[0], Wa.data_ptr(), E, H, H, dh0[NL - 1], accumulate=True)
+        for l in range(NL):
+            wi, wh, bi, bh = dec.lstm.layer(l)
+            if not wi.requires_grad:
+                continue
+            DG2 = DG[l].view(T * B, 4 * H)
+            inp_all = s["X"] if l == 0 else Hall[l - 1]
+            k_in = wi.shape[1]
+            ops.gemm_tn_acc(DG2, inp_all.view(T * B, k_in), gb(wi).data_ptr(), 4 * H, k_in, k_in)
             if T > 1:
-                ops.gemm_tn_acc(DG[1:].reshape((T - 1) * B, 4 * H), Hall[:-1].reshape((T - 1) * B, H), gb(wh).data_ptr(), 4 * H, H, H)
+                ops.gemm_tn_acc(DG[l, 1:].reshape((T - 1) * B, 4 * H), Hall[l, :-1].reshape((T - 1) * B, H), gb(wh).data_ptr(), 4 * H, H, H)
             else:
                 gb(wh)
+            if h0 is not None:
+                ops.gemm_tn_acc(DG[l, 0], h0[l], gb(wh).data_ptr(), 4 * H, H, H)
             ops.colsum_into(DG2, gb(bi))
             ops.colsum_into(DG2, gb(bh))
         if Wa.requires_grad:
             if T > 1:
-                ops.gemm_tn_acc(dHP[1:].reshape((T - 1) * B, E), Hall[:-1].reshape((T - 1) * B, H), gb(Wa).data_ptr(), E, H, H)
+                ops.gemm_tn_acc(dHP[1:].reshape((T - 1) * B, E), Htop[:-1].reshape((T - 1) * B, H), gb(Wa).data_ptr(), E, H, H)
             else:
                 gb(Wa)
+            if h0 is not None:
+                ops.gemm_tn_acc(dHP[0], h0[NL - 1], gb(Wa).data_ptr(), E, H, H)
             ops.colsum_into(dHP.view(T * B, E), gb(dec.attention.bias))
         if dec.embedding.weight.requires_grad:
             ops.embedding_bwd(s["captions"], dX.view(T * B, E), gb(dec.embedding.weight))
+        dc0 = torch.stack([hnn._c(c) for c in carry_c], 0) if want_state else None
         ctx.saved = None
-        return (dfeats,) + (None,) * (len(ctx.needs_input_grad) - 1)
+        return (dfeats, None, None, dh0, dc0) + (None,) * (len(ctx.needs_input_grad) - 5)
 
 
 class CompactLSTMDecoder(nn.Module):
@@ -346,8 +380,6 @@ class CompactLSTMDecoder(nn.Module):
 
     def __init__(self, vocab_size, embed_size=256, hidden_size=256, num_layers=1, dropout=0.1):
         super().__init__()
-        if num_layers != 1:
-            raise NotImplementedError("the compact decoder is built single-layer, as the reference configures it (:74,:88-94)")
         self.embed_size, self.hidden_size, self.num_layers, self.vocab_size = embed_size, hidden_size, num_layers, vocab_size
         self.embedding = hnn.Embedding(vocab_size, embed_size)
         nn.init.uniform_(self.embedding.weight, -0.1, 0.1)
@@ -371,32 +403,37 @@ class CompactLSTMDecoder(nn.Module):
         return x, w
 
     def forward(self, image_features, captions, hidden=None):
-        if hidden is not None:
-            raise NotImplementedError("a caller-supplied initial state is not used by the reference's compact pipeline")
+        """hidden: optional (h0, c0), each (num_layers, B, H) (reference :140,:155-156); None = zero state."""
         params = [p for p in self.parameters() if p.requires_grad]
-        logits, hs, attw = CompactDecoderFn.apply(image_features, captions, self, *params)
+        h0, c0 = hidden if hidden is not None else (None, None)
+        logits, hs, attw = CompactDecoderFn.apply(image_features, captions, self, h0, c0, *params)
         return logits, list(hs.unbind(0)), list(attw.unbind(0))
 
     @torch.no_grad()
     def greedy(self, image_features, max_length=20, start_id=1):
         feats = hnn._c(image_features)
         B, P, E = feats.shape
-        H, V = self.hidden_size, self.vocab_size
+        H, V, NL = self.hidden_size, self.vocab_size, self.num_layers
         dev = feats.device
-        wi, wh, bi, bh = self.lstm.layer(0)
-        h, c = ops.zeros(B, H, device=dev), ops.zeros(B, H, device=dev)
-        hn, cn = ops.empty(B, H, device=dev), ops.empty(B, H, device=dev)
+        h = [ops.zeros(B, H, device=dev) for _ in range(NL)]
+        c = [ops.zeros(B, H, device=dev) for _ in range(NL)]
+        hn = [ops.empty(B, H, device=dev) for _ in range(NL)]
+        cn = [ops.empty(B, H, device=dev) for _ in range(NL)]
         hp, w, x = ops.empty(B, E, device=dev), ops.empty(B, P, device=dev), ops.empty(B, E, device=dev)
         tok = torch.full((B,), start_id, dtype=torch.int64, device=dev)
         ids = torch.empty(max_length, B, dtype=torch.int64, device=dev)
         logits = ops.empty(max_length, B, V, device=dev)
         for t in range(max_length):
             emb = ops.embedding_fwd(tok, self.embedding.weight)
-            ops.gemm_nt(h, self.attention.weight.data_ptr(), E, H, H, hp, bias=self.attention.bias)
+            ops.gemm_nt(h[NL - 1], self.attention.weight.data_ptr(), E, H, H, hp, bias=self.attention.bias)
             ops.dot_attn_fwd(hp, feats, emb, w, x)
-            ops.lstm_layer_fwd(x, h, wi, wh, bi, bh, c, None, cn, hn)
-            h, hn, c, cn = hn, h, cn, c
-            ops.linear_fwd(h, self.output_projection.weight, self.output_projection.bias, out=logits[t])
+            inp = x
+            for l in range(NL):
+                wi, wh, bi, bh = self.lstm.layer(l)
+                ops.lstm_layer_fwd(inp, h[l], wi, wh, bi, bh, c[l], None, cn[l], hn[l])
+                h[l], hn[l], c[l], cn[l] = hn[l], h[l], cn[l], c[l]
+                inp = h[l]
+            ops.linear_fwd(h[NL - 1], self.output_projection.weight, self.output_projection.bias, out=logits[t])
             tok = ops.argmax_rows(logits[t])
             ids[t] = tok
         return ids, logits

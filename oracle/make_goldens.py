@@ -443,6 +443,34 @@ def golden_compact():
     npz("compact_student.npz", **out)
 
 
+def golden_compact_decoder_layers():
+    """The reference's CompactLSTMDecoder with num_layers = 2 and a caller-supplied (h0, c0) (student_model_compact.py:72-111,
+    :140-190): forward outputs and gradients (parameters, features, the state) on fixed features — VERDICT r02 item 10."""
+    import student_model_compact as ref_compact
+    torch.manual_seed(0)
+    Vd, E, H, NL, T, B = 500, 128, 256, 2, 6, 3
+    dec = ref_compact.CompactLSTMDecoder(Vd, E, H, NL, 0.0)
+    apply_seeded_init(dec, seed=9)
+    dec.train()
+    g = torch.Generator().manual_seed(4)
+    feats = torch.randn(B, 49, E, generator=g).requires_grad_(True)
+    caps = torch.randint(4, Vd, (T, B), generator=g)
+    h0 = (torch.randn(NL, B, H, generator=g) * 0.5).requires_grad_(True)
+    c0 = (torch.randn(NL, B, H, generator=g) * 0.5).requires_grad_(True)
+    dl = torch.randn(T, B, Vd, generator=g) * 1e-2
+    out, hids, attw = dec(feats, caps, hidden=(h0, c0))
+    (out * dl).sum().backward()
+    sd = dict(dec.named_parameters())
+    res = dict(feats=feats.detach(), caps=caps, h0=h0.detach(), c0=c0.detach(), dl=dl, logits=out.detach(), hid_last=hids[-1].detach(),
+               attw0=attw[0].detach(), dfeats=feats.grad, dh0=h0.grad, dc0=c0.grad, dims=np.array([Vd, E, H, NL, T, B]))
+    for k in ("lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.weight_ih_l1", "lstm.weight_hh_l1", "lstm.bias_ih_l1", "attention.weight",
+              "embedding.weight", "output_projection.weight"):
+        res["g:" + k] = sd[k].grad[::4, ::4] if sd[k].dim() == 2 else sd[k].grad
+    out0, _, _ = dec(feats.detach(), caps)                      # no state given = zero state
+    res["logits_zero_state"] = out0.detach()
+    npz("compact_decoder_2layer.npz", **res)
+
+
 # ------------------------------------------------------------------ (9) teacher beam search (SURVEY §8(f) N1)
 def golden_beam():
     t = build_teacher()
@@ -529,6 +557,6 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "kd_step_b16", "compact", "beam", "optloss"]
     fns = {"counts": golden_param_counts, "losses": golden_losses, "projector": golden_projector,
            "refinement": golden_refinement, "decoders": golden_decoders, "cfg1": golden_cfg1,
-           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "kd_step_b16_autocast": golden_kd_step_b16_autocast, "kd_step_cfg5_b16": golden_kd_step_cfg5_b16, "compact": golden_compact, "beam": golden_beam, "optloss": golden_optloss}
+           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "kd_step_b16_autocast": golden_kd_step_b16_autocast, "kd_step_cfg5_b16": golden_kd_step_cfg5_b16, "compact": golden_compact, "compact_layers": golden_compact_decoder_layers, "beam": golden_beam, "optloss": golden_optloss}
     for w in which:
         fns[w]()

@@ -35,7 +35,7 @@ CASES = [("NT 4096^3", 0, 4096, 4096, 4096, None, 0), ("fc1 12608x1536x384 gelu"
          ("conv1x1 14x14 256->1024", 3, B * 14 * 14, 1024, 256, (B, 14, 14, 256, 14, 14, 1024, 1, 1, 1, 0), 0),
          ("conv3x3 28x28 128->128", 3, B * 28 * 28, 128, 1152, (B, 28, 28, 128, 28, 28, 128, 3, 3, 1, 1), 0),
          ("conv1x1 56x56 64->256", 3, B * 56 * 56, 256, 64, (B, 56, 56, 64, 56, 56, 256, 1, 1, 1, 0), 0)]
-TILES = [1, 65, 129, 4, 2]
+TILES = [1, 65, 129, 3, 4, 2]
 
 
 def desc(torch, IckGemm, bufs, op, M, N, K, conv, act, tile, out):
@@ -76,9 +76,17 @@ def main():
 
     if mode == "run":
         print("times in us (TF/s); columns = ICK_EXP", ns, flush=True)
+        ytile = torch.empty(1 << 26, device="cuda")
         for name, op, M, N, K, conv, act in CASES:
-            for tile in TILES:
+            for ti, tile in enumerate(TILES):
                 line = f"{name:26s} tile {tile:3d}"
+                if len(ns) == 1:      # one library: every tile's result against the first tile's (fp32 reorder noise only)
+                    d0 = desc(torch, IckGemm, bufs, op, M, N, K, conv, act, tile, ytile if ti == 0 else y)
+                    assert libs[ns[0]].ick_gemm_f32(ctypes.byref(d0), st) == 0
+                    torch.cuda.synchronize()
+                    if ti > 0:
+                        e = ((y[:M * N] - ytile[:M * N]).abs().max() / ytile[:M * N].abs().max()).item()
+                        line += f" [vs tile {TILES[0]}: {e:.1e}{'' if e < 1e-5 else ' ERR'}]"
                 for j, n in enumerate(ns):
                     L = libs[n]
                     d = desc(torch, IckGemm, bufs, op, M, N, K, conv, act, tile, yref if j == 0 else y)
