@@ -123,8 +123,17 @@ void igemm_glds_kernel(const P p) {
   static_assert(WM >= 32 && WN >= 32, "a wave owns at least one 32x32 MFMA tile");
   constexpr int PA = BM / (8 * DW), PB = BN / (8 * DW);   // LDS-DMA instructions per issuing thread per k-tile
   constexpr int A_SZ = BM * BK, B_SZ = BN * BK, BUF = A_SZ + B_SZ;
-  constexpr int A_TPK = BM / 4, B_TPK = BN / 4;        // lanes per k-row of an x-contiguous image
+  // X16: NATIVE 16-bit operands that are x-contiguous (TN, CONV_WGRAD with TERMS 5 / 6; round 3).  Extents stay in ELEMENTS
+  // (halves).  A k-tile is 64 k-rows; the LDS images are [64 k][BX halves] (the same bytes as the fp32 [32 k][BX] image), a
+  // lane's 16 bytes are 8 halves along x, and the fragment is TRANSPOSED ON THE READ (ds_read_b64_tr_b16, the read pattern of
+  // igemm_bf16.hip).  The DMA cannot pad rows, so the 64-byte granules of a row are XOR-swizzled by (k-row & (granules - 1))
+  // through the source address: the four k-rows a 32-lane read group touches then sit in four different 16-bank groups.
+  constexpr bool X16 = TERMS >= 5 && !AK && !BKc;
+  static_assert(TERMS < 5 || (AK && BKc) || X16, "native 16-bit operands: both k-contiguous or both x-contiguous");
+  constexpr int BKE = X16 ? 64 : BK;                    // k extent of a k-tile in the kernel's k units
+  constexpr int A_TPK = X16 ? BM / 8 : BM / 4, B_TPK = X16 ? BN / 8 : BN / 4;   // lanes per k-row of an x-contiguous image
   constexpr int A_RPI = 64 / A_TPK, B_RPI = 64 / B_TPK;  // k-rows per DMA instruction (x-contiguous)
+  constexpr int A_NG = X16 ? BM / 32 : 1, B_NG = X16 ? BN / 32 : 1;             // 64-byte granules per image row (X16)
   constexpr bool H16OUT = TERMS != 0 && TERMS != 3;       // variants that can write C / read the residual as 16-bit (P.c16 / P.r16)
 
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF];
@@ -163,7 +172,7 @@ void igemm_glds_kernel(const P p) {
   const long coff = zo * p.sCo + zi * p.sCi;
   const int kbeg = split * p.kps;
   const int kend = OP == ICK_OP_CONV_DGRAD_S2 ? kcls : min(p.K, kbeg + p.kps);
-  const int nkt = (kend - kbeg + BK - 1) / BK;
+  const int nkt = (kend - kbeg + BKE - 1) / BKE;
 
   // ---------------------------------------------------------------- per-thread DMA state
   // k-contiguous: DMA instruction q = wave*P + i covers rows 8q..8q+7; lane l -> row 8q + (l>>3), linear chunk slot l&7,
@@ -195,6 +204,12 @@ void igemm_glds_kernel(const P p) {
         a_y[i] = iy + p.pad; a_x[i] = ix + p.pad;
         a_ptr[i] = Ag + (long)b * p.Ho * p.Wo * p.Cout;
       }
+    } else if constexpr (X16) {   // A [K][M] halves: lane -> (k-row, 8 m) with the row's 64-byte granules swizzled by the k-row
+      const int krow = q * A_RPI + lane / A_TPK, slot = lane % A_TPK;
+      const int m = m0 + (((((slot >> 2) ^ (krow & (A_NG - 1))) << 2) | (slot & 3)) << 3);
+      a_ok[i] = m < p.M;
+      a_ptr[i] = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(Ag) + m);
+      a_y[i] = krow; a_x[i] = 0; a_kq[i] = 0;
     } else {  // A stored [K][M]: instruction q covers k-rows q*A_RPI .. ; lane -> (k-row, 4 m)
       const int m = m0 + (lane % A_TPK) * 4;
       a_ok[i] = m < p.M;
@@ -207,7 +222,7 @@ void igemm_glds_kernel(const P p) {
   // every lane's pixel by BK, so the two integer divisions per piece per k-tile of the direct form (~50 VALU instructions
   // each) become a handful of adds and compares.  Pieces are issued in k-tile order, which is what makes this valid.
   int w_img[PB], w_oy[PB], w_ox[PB];
-  const int w_q = OP == ICK_OP_CONV_WGRAD ? BK / max(p.Wo, 1) : 0, w_r = OP == ICK_OP_CONV_WGRAD ? BK - w_q * p.Wo : 0;
+  const int w_q = OP == ICK_OP_CONV_WGRAD ? BKE / max(p.Wo, 1) : 0, w_r = OP == ICK_OP_CONV_WGRAD ? BKE - w_q * p.Wo : 0;
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int q = dw * PB + i;
@@ -218,18 +233,23 @@ void igemm_glds_kernel(const P p) {
       b_ok[i] = n < p.N;
       b_ptr[i] = Bg + (long)n * p.ldb + b_kq[i]; b_y[i] = 0;
     } else {
-      const int n = n0 + (lane % B_TPK) * 4;
+      const int krow = q * B_RPI + lane / B_TPK, slot = lane % B_TPK;
+      const int n = X16 ? n0 + (((((slot >> 2) ^ (krow & (B_NG - 1))) << 2) | (slot & 3)) << 3) : n0 + slot * 4;
       b_ok[i] = n < p.N;
-      b_y[i] = q * B_RPI + lane / B_TPK; b_kq[i] = 0;
+      b_y[i] = krow; b_kq[i] = 0;
+      auto belem = [&](long e) {   // Bg + e elements (halves for X16)
+        if constexpr (X16) return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(Bg) + e);
+        else return Bg + e;
+      };
       if constexpr (OP == ICK_OP_CONV_WGRAD) {
         const int tap = n / p.Cin; const int ci = n - tap * p.Cin;
         b_r = tap / p.S; b_s = tap - b_r * p.S;
-        b_ptr[i] = Bg + ci;
+        b_ptr[i] = belem(ci);
         const int hw = p.Ho * p.Wo;
         const int k = kbeg + b_y[i];
         w_img[i] = k / hw; const int rem = k - w_img[i] * hw; w_oy[i] = rem / p.Wo; w_ox[i] = rem - w_oy[i] * p.Wo;
       } else {
-        b_ptr[i] = Bg + n;
+        b_ptr[i] = belem(n);
       }
     }
   }
@@ -243,7 +263,7 @@ void igemm_glds_kernel(const P p) {
   // between the MFMA blocks; the epilogue drains them before it reuses the buffers).
   struct KTile { int k0, r, s, c0, tap; bool valid; };
   auto ktile = [&](int kt, bool valid) -> KTile {
-    KTile t; t.k0 = kbeg + kt * BK; t.r = t.s = t.c0 = t.tap = 0; t.valid = valid;
+    KTile t; t.k0 = kbeg + kt * BKE; t.r = t.s = t.c0 = t.tap = 0; t.valid = valid;
     if constexpr (OP == ICK_OP_CONV_FWD) {
       const int tap = t.k0 / p.Cin; t.c0 = t.k0 - tap * p.Cin; t.r = tap / p.S; t.s = tap - t.r * p.S;
     } else if constexpr (OP == ICK_OP_CONV_DGRAD) {
@@ -253,6 +273,11 @@ void igemm_glds_kernel(const P p) {
       t.r = r0 + 2 * (q / ns); t.s = s0 + 2 * (q % ns); t.tap = t.r * p.S + t.s;
     }
     return t;
+  };
+  // pointer + element offset for the x-contiguous operands (elements are halves in the X16 variants)
+  auto eoff = [](const float* ptr, long e) -> const float* {
+    if constexpr (X16) return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(ptr) + e);
+    else return ptr + e;
   };
   // piece q of a k-tile's DMA into buffer buf: q < PA -> A instruction q of this wave, else B instruction q - PA
   auto issue_piece = [&](const KTile& t, int q, int buf) {
@@ -285,7 +310,7 @@ void igemm_glds_kernel(const P p) {
         src = a_ptr[i] + ((long)oy * p.Wo + ox) * p.Cout + t.c0 + a_kq[i];
       } else {  // A [K][M]
         const int k = k0 + a_y[i];
-        ok = a_ok[i] && k < kend; src = a_ptr[i] + (long)k * p.lda;
+        ok = a_ok[i] && k < kend; src = eoff(a_ptr[i], (long)k * p.lda);
       }
       glds16((ok && t.valid) ? src : zpage, dst);
     } else {
@@ -301,13 +326,13 @@ void igemm_glds_kernel(const P p) {
         const int k = k0 + b_y[i];
         const int iy = w_oy[i] * p.stride - p.pad + b_r, ix = w_ox[i] * p.stride - p.pad + b_s;
         ok = b_ok[i] && k < kend && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        src = b_ptr[i] + (((long)w_img[i] * p.H + iy) * p.W + ix) * p.Cin;
+        src = eoff(b_ptr[i], (((long)w_img[i] * p.H + iy) * p.W + ix) * p.Cin);
         w_ox[i] += w_r; w_oy[i] += w_q;                     // the same piece of the NEXT k-tile: BK pixels on
         if (w_ox[i] >= p.Wo) { w_ox[i] -= p.Wo; ++w_oy[i]; }
         while (w_oy[i] >= p.Ho) { w_oy[i] -= p.Ho; ++w_img[i]; }
       } else {  // B [K][N]
         const int k = k0 + b_y[i];
-        ok = b_ok[i] && k < kend; src = b_ptr[i] + (long)k * p.ldb;
+        ok = b_ok[i] && k < kend; src = eoff(b_ptr[i], (long)k * p.ldb);
       }
       glds16((ok && t.valid) ? src : zpage, dst);
     }
@@ -322,8 +347,26 @@ void igemm_glds_kernel(const P p) {
 
   // fragments of k-group j (8 k) of tile-row/column t: element e feeds MFMA e (k-slots {8j+e, 8j+4+e})
   const int frow = lane & 31, fh = lane >> 5, fsw = (frow >> 1) & 7;
+  // X16: transposed fragment of MFMA k-step j (16 k-rows) of 32 image columns starting at col0 (ds_read_b64_tr_b16 twice: the
+  // read pattern of igemm_bf16.hip tr_read8 — 16-lane group tg, block row tq, 4-column piece tp), swizzled like the DMA wrote it
+  const int xtg = lane >> 4, xtq = (lane >> 2) & 3, xtp = lane & 3;
+  auto frag_x16 = [&](const float* img, int j, int col0, int bx, int ng) -> float4 {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4* lds_p;
+    const int krow = j * 16 + (xtg >> 1) * 8 + xtq;
+    const int col = col0 + (xtg & 1) * 16 + xtp * 4;                       // halves; 64-byte granule = col >> 5
+    const unsigned short* base = reinterpret_cast<const unsigned short*>(img);
+    const unsigned short* q = base + krow * bx + ((((col >> 5) ^ (krow & (ng - 1))) << 5) | (col & 31));
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(q));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(q + 4 * bx));   // k-rows + 4: same swizzle (granule counts are 2 or 4)
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(float4, v);
+  };
   auto frag_a = [&](const float* Ab, int j, int i) -> float4 {
-    if constexpr (AK) {
+    if constexpr (X16) {
+      return frag_x16(Ab, j, wm * WM + i * 32, BM, A_NG);
+    } else if constexpr (AK) {
       return *reinterpret_cast<const float4*>(Ab + (wm * WM + i * 32 + frow) * BK + (((2 * j + fh) ^ fsw) << 2));
     } else {
       const float* q = Ab + (8 * j + 4 * fh) * BM + wm * WM + i * 32 + frow;
@@ -331,7 +374,9 @@ void igemm_glds_kernel(const P p) {
     }
   };
   auto frag_b = [&](const float* Bb, int j, int t) -> float4 {
-    if constexpr (BKc) {
+    if constexpr (X16) {
+      return frag_x16(Bb, j, wn * WN + t * 32, BN, B_NG);
+    } else if constexpr (BKc) {
       return *reinterpret_cast<const float4*>(Bb + (wn * WN + t * 32 + frow) * BK + (((2 * j + fh) ^ fsw) << 2));
     } else {
       const float* q = Bb + (8 * j + 4 * fh) * BN + wn * WN + t * 32 + frow;
@@ -762,6 +807,16 @@ constexpr int kBodySlots = 2 * kCUs; // 128x128 workgroups resident at once (64 
 
 template <int OP, int TERMS>
 int launch_tile(const P& p, int nz, hipStream_t st, int tile, int m_begin = 0, int m_end = 0) {
+  if constexpr (TERMS >= 5 && !a_kcontig(OP)) {   // native 16-bit x-contiguous operands (TN, CONV_WGRAD): the two-buffer tiles only
+    switch (tile & (64 | 15)) {
+      case 1: return launch<OP, 128, 128, 2, TERMS>(p, nz, st, m_begin, m_end);
+      case 2: return launch<OP, 64, 64, 2, TERMS>(p, nz, st, m_begin, m_end);
+      case 4: return launch<OP, 64, 128, 2, TERMS>(p, nz, st, m_begin, m_end);
+      case 65: return launch<OP, 128, 128, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
+      case 67: return launch<OP, 128, 64, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
+      default: return launch<OP, 128, 64, 2, TERMS>(p, nz, st, m_begin, m_end);
+    }
+  } else
   switch (tile) {           // +16: three LDS buffers (two tiles of prefetch) instead of two
     case 2: return launch<OP, 64, 64, 2, TERMS>(p, nz, st, m_begin, m_end);
     case 3: return launch<OP, 128, 64, 2, TERMS>(p, nz, st, m_begin, m_end);
@@ -837,7 +892,9 @@ int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
   if constexpr (TERMS >= 5) {   // both operands k-contiguous: the only ops whose 16-bit image the fp32 addressing can carry
     if (d->op == ICK_OP_NT) return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
     if (d->op == ICK_OP_CONV_FWD) return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
-    return ick::fail(-1, "igemm (native 16-bit, LDS-DMA): NT and CONV_FWD only, got op %d", d->op);
+    if (d->op == ICK_OP_TN) return dispatch_tile<ICK_OP_TN, TERMS>(p, nz, st, d->tile);               // x-contiguous operands (X16)
+    if (d->op == ICK_OP_CONV_WGRAD) return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS>(p, nz, st, d->tile);
+    return ick::fail(-1, "igemm (native 16-bit, LDS-DMA): NT, CONV_FWD, TN and CONV_WGRAD only, got op %d", d->op);
   } else
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);

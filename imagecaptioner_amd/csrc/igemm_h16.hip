@@ -6,6 +6,7 @@
 //   * everything else (weight gradients, stride-2 data gradients, NN / TN): the register-staged kernel of igemm_bf16.hip with
 //     IN16 = true (8-byte fetches of four halves, transposed LDS reads).
 #include "igemm_params.h"
+#include <cstdlib>
 
 namespace ickg {
 bool glds_eligible(const IckGemm* d);                                           // igemm_f32_glds.hip
@@ -74,6 +75,19 @@ extern "C" int ick_gemm_h16(const IckGemm* d0, int fp16, void* stream) {
     const bool kc = d0->op == ICK_OP_NT || d0->op == ICK_OP_CONV_FWD;
     const bool units = kc && !(d0->tile & 256) && p.K % 8 == 0 && p.lda % 8 == 0 && p.ldb % 8 == 0 && nz == 1 && p.splitk == 1 &&
                        (d0->op != ICK_OP_CONV_FWD || p.Cin % 64 == 0);
+    // x-contiguous operands on the LDS-DMA kernel (round 3; igemm_glds_impl.h X16): weight gradients and TN products in
+    // ELEMENT extents, k-tiles of 64 rows, transposed LDS reads.  8-half chunks must not straddle a row end or a filter tap.
+    static const bool x16_on = [] { const char* e = getenv("ICK_X16_GLDS"); return !(e && e[0] == '0'); }();
+    const bool xc = (d0->op == ICK_OP_TN || d0->op == ICK_OP_CONV_WGRAD) && x16_on && !(d0->tile & 256) && nz == (p.splitk > 1 ? p.splitk : 1) &&
+                    p.M % 8 == 0 && p.N % 8 == 0 && !p.c16 && !p.r16 &&
+                    (d0->op == ICK_OP_TN ? (p.lda % 8 == 0 && p.ldb % 8 == 0) : (p.Cin % 8 == 0 && p.Cout % 8 == 0));
+    if (xc) {
+      IckGemm dx = *d0;
+      dx.tile &= 255;
+      P px; int nzx = 1;
+      if (int rc = prepare(&dx, 64, px, nzx, "ick_gemm_h16")) return rc;      // split-K slices in multiples of the 64-row k-tile
+      return fp16 ? run_glds_h16_t6(&dx, px, nzx, st) : run_glds_h16_t5(&dx, px, nzx, st);
+    }
     if (!units) return run_regs_h16(d0, fp16, p, nz, st);
   }
   IckGemm dd = *d0;

@@ -491,7 +491,7 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int,
     _, H, W, Cin = x.shape
     _, R, S, _ = dw.shape
     assert dy.is_contiguous() and x.is_contiguous() and dw.is_contiguous() and dy.dtype == x.dtype and dw.dtype == _F32
-    io = dict(h16=_h16(dy), default_tile=3) if _h16(dy) is not None else {}      # 128x64: best or within 3 % on every shape measured
+    io = dict(h16=_h16(dy), default_tile=67) if _h16(dy) is not None else {}     # 128x64, eight waves: best or within 3 % on every shape measured
     K = Nb * Ho * Wo
     N = R * S * Cin
     if R == 1 and S == 1 and stride == 1 and pad == 0 and not io and _WGRAD_1X1_AS_TN[0]:
@@ -506,11 +506,11 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int,
             gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, Cin, K, Cout, Cin, Cin, accumulate=True, default_tile=3)
         return
     if splitk <= 0 and io:
-        # native 16-bit operands (measured, tools/bench_wgrad16.py): ~784 pixels per split is the sweet spot on every layer3 /
-        # layer4 shape (1024x256x12544: 40 us at 16 splits against 56 at 48; 2048x512x3136: 39 us at 4 against 54 at 12),
-        # capped so that the grid stays within ~6 workgroups per CU
+        # native 16-bit operands on the LDS-DMA kernel (round 3, tools/bench_wgrad16.py, profiles/r03_wgrad16_lds_dma.log): the
+        # grid wants ~560 workgroups of 128 x 64 (256x2304x12544: 42 us = 350 TF at 8 splits against 53 at 16 and 75 on the
+        # register-staged kernel; 512x4608x3136: 44 us at 2 splits), never fewer than ~400 pixels per split
         tiles = ((Cout + 127) // 128) * ((N + 63) // 64)
-        splitk = max(1, min(64, K // 784, 1536 // max(tiles, 1)))
+        splitk = max(1, min(64, K // 392, round(560 / max(tiles, 1))))
     if splitk <= 0:
         tiles = ((Cout + 127) // 128) * ((N + 127) // 128)
         splitk = max(1, min(64, 768 // max(tiles, 1), K // 128))

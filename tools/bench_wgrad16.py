@@ -35,10 +35,16 @@ for (H, Cin, Cout, R) in [(14, 256, 256, 3), (14, 256, 1024, 1), (14, 1024, 256,
     conv = (B, H, H, Cin, H, H, Cout, R, R, 1, pad)
     fl = 2.0 * Cout * N * K
     print(f"wgrad Cout {Cout} N {N} K {K}  ({fl / 1e9:.1f} GF)")
-    for tile in ((1, 2, 3, 4) if dt is not None else (3, 19, 67, 83, 259)):
+    # 16-bit operands: 259 = the register-staged IN16 kernel, the others the LDS-DMA kernel with transposed reads (round 3)
+    ops.gemm_raw(ops.OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, conv=conv, tile=259, h16=dt, accumulate=True)
+    ref = dw.clone()
+    for tile in ((259, 1, 2, 3, 4, 65, 67) if dt is not None else (3, 19, 67, 83, 259)):
         line = []
         for sk in (1, 2, 4, 8, 16, 24, 48):
             kw = dict(splitk=sk) if sk > 1 else dict(accumulate=True)
-            t = timeit(lambda: ops.gemm_raw(ops.OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, conv=conv, tile=tile, h16=dt, **kw))
-            line.append(f"sk{sk:2d} {t:6.1f}us {fl / t / 1e6:4.0f}TF")
-        print(f"  tile {tile}: " + "  ".join(line))
+            f = lambda: ops.gemm_raw(ops.OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, conv=conv, tile=tile, h16=dt, **kw)
+            dw.zero_(); f(); torch.cuda.synchronize()
+            err = ((dw - ref).abs().max() / ref.abs().max()).item()
+            t = timeit(f)
+            line.append(f"sk{sk:2d} {t:6.1f}us {fl / t / 1e6:4.0f}TF{'' if err < 1e-4 else ' ERR %.1e' % err}")
+        print(f"  tile {tile:3d}: " + "  ".join(line))
