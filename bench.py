@@ -51,7 +51,8 @@ def measured_traffic(batch: int, precision: str = "f32"):
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command, gfx950 x2 fetch correction;
     tools/measure_traffic.py).  PMC counters cannot be collected inside the timed run itself, so the line names its
     source; (None, None) for other batch sizes / precisions without a committed run."""
-    names = {"f32": ("r02k_traffic.json", "r02_traffic.json", "r01_traffic.json"), "fp16": ("r02k_traffic_fp16.json",)}.get(precision, ())
+    names = {"f32": ("r03_traffic.json", "r02k_traffic.json", "r02_traffic.json", "r01_traffic.json"),
+             "fp16": ("r03_traffic_fp16.json", "r02k_traffic_fp16.json")}.get(precision, ())
     for name in names:
         try:
             t = json.load(open(os.path.join(ROOT, "profiles", name)))

@@ -164,7 +164,11 @@ extern "C" int ick_attention_fwd_d64(const float* q, int64_t qld, int64_t qbs, c
   AP p{q, k, v, o, qld, kld, vld, old, qbs, kbs, vbs, obs, H, Lq, Lk, causal, scale};
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int tiles = (Lq + 31) / 32;
-  if (tiles >= 4) {
+  if (tiles == 7) {
+    // the ViT's 197 tokens: seven waves in ONE workgroup per (batch, head) share each K / V chunk — with four-wave
+    // workgroups the second one (69 valid queries of 128) re-stages every chunk for 2.2 waves of work
+    ICK_LAUNCH((attn_fwd_kernel<7>), dim3(B * H, 1), dim3(448), 0, st, p);
+  } else if (tiles >= 4) {
     ICK_LAUNCH((attn_fwd_kernel<4>), dim3(B * H, (tiles + 3) / 4), dim3(256), 0, st, p);
   } else if (tiles >= 2) {
     ICK_LAUNCH((attn_fwd_kernel<2>), dim3(B * H, (tiles + 1) / 2), dim3(128), 0, st, p);
