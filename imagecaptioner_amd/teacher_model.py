@@ -14,6 +14,9 @@ as parameter holders (names + init identical to the reference's).  Teacher train
 from __future__ import annotations
 
 import math
+import os
+
+from typing import Optional
 
 import torch
 import torch.nn as nn
@@ -258,16 +261,10 @@ class CaptioningTeacher(nn.Module):
         return ops.linear_fwd(xn, self.fc_out.weight, self.fc_out.bias)
 
     @torch.no_grad()
-    def beam_search(self, images, start_id: int, end_id, max_length: int = 20, beam_size: int = 5):
-        """Batched, KV-cached beam search over B images at once, no host synchronisation inside the loop.  Returns ONE host
-        tensor bundle {fin_seq (B,W,Tcap) int32, fin_score (B,W) raw log-prob sums, fin_len, nfin, seq, score, width}: the
-        finished hypotheses of every image in finishing order plus the beams still live after max_length steps.
-        Same search as the reference (:144-228): only beam 0 is real before the first expansion, `width` candidates survive
-        a step, a candidate ending in <END> leaves as a finished hypothesis and narrows that image's beam by one."""
-        if self.training:
-            raise NotImplementedError("the HIP teacher is forward-only/eval")
+    def _beam_search_device(self, images, start_id: int, end_id, max_length: int, W: int):
+        """the device side of beam_search: (state int32 block, offsets, index of the live sequence buffer)"""
         dev = images.device
-        B, W, V = images.shape[0], int(beam_size), self.vocab_size
+        B, V = images.shape[0], self.vocab_size
         Tcap = max_length + 1
         memory = self.project_memory(self.encoder.forward_features(images))                     # (B,197,E)
         L, E = memory.shape[1], memory.shape[2]
@@ -299,6 +296,48 @@ class CaptioningTeacher(nn.Module):
             ops.beam_step(logits, score, width, seq[cur], seq[cur ^ 1], anc[cur], anc[cur ^ 1], tok, fin_seq, fin_score, fin_len,
                           nfin, t, -1 if end_id is None else int(end_id))
             cur ^= 1
+        return state, offs, cur
+
+    @torch.no_grad()
+    def beam_search(self, images, start_id: int, end_id, max_length: int = 20, beam_size: int = 5, use_graph: Optional[bool] = None):
+        """Batched, KV-cached beam search over B images at once, no host synchronisation inside the loop.  Returns ONE host
+        tensor bundle {fin_seq (B,W,Tcap) int32, fin_score (B,W) raw log-prob sums, fin_len, nfin, seq, score, width}: the
+        finished hypotheses of every image in finishing order plus the beams still live after max_length steps.
+        Same search as the reference (:144-228): only beam 0 is real before the first expansion, `width` candidates survive
+        a step, a candidate ending in <END> leaves as a finished hypothesis and narrows that image's beam by one.
+        use_graph (default: on, ICK_BEAM_GRAPH=0 switches it off): the ~1000 small launches of the ViT pass + max_length decode
+        steps are captured once per (batch, beam, length, token ids, parameter versions) into a hipGraph and replayed — the
+        search is launch-bound otherwise (320 beam rows per step)."""
+        if self.training:
+            raise NotImplementedError("the HIP teacher is forward-only/eval")
+        B, W = images.shape[0], int(beam_size)
+        Tcap = max_length + 1
+        if use_graph is None:
+            use_graph = os.environ.get("ICK_BEAM_GRAPH", "1") != "0"
+        if use_graph and images.is_cuda:
+            key = (tuple(images.shape), W, max_length, start_id, end_id, tuple((q.data_ptr(), q._version) for q in self.parameters()))
+            cache = self.__dict__.setdefault("_ick_beam_graphs", {})
+            ent = cache.get(key)
+            if ent is None:
+                buf = torch.empty_like(images)
+                buf.copy_(images)
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self._beam_search_device(buf, start_id, end_id, max_length, W)      # warm-up: allocator, lazy caches
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    state, offs, cur = self._beam_search_device(buf, start_id, end_id, max_length, W)
+                while len(cache) >= 4:                                                   # each entry owns its K/V caches
+                    cache.pop(next(iter(cache)))
+                ent = cache[key] = (g, buf, state, offs, cur)
+            g, buf, state, offs, cur = ent
+            buf.copy_(images)
+            g.replay()
+        else:
+            state, offs, cur = self._beam_search_device(images, start_id, end_id, max_length, W)
         host = state.cpu()                                                                      # the search's only device->host copy
         hp = lambda i: host[offs[i]:offs[i + 1]]
         return {"fin_seq": hp(0).view(B, W, Tcap), "fin_score": hp(1).view(torch.float32).view(B, W), "fin_len": hp(2).view(B, W),

@@ -25,3 +25,14 @@ CFG5_KEYS.update({
     "decoder.attention.weight": np.s_[::4, ::8], "decoder.output_projection.3.weight": np.s_[::40, ::4],
     "decoder.embedding.weight": np.s_[::40, ::4],
 })
+
+# CompactCaptioningStudent at B = 16 (tests/golden/compact_student_B16.npz): MobileNetV2 trunk tensors + head / decoder tensors
+COMPACT_B16_KEYS = {
+    "encoder.backbone.18.0.weight": np.s_[::8, ::4, 0, 0], "encoder.backbone.17.conv.1.0.weight": np.s_[::4, 0],
+    "encoder.backbone.17.conv.2.weight": np.s_[::4, ::8, 0, 0], "encoder.backbone.14.conv.0.0.weight": np.s_[::8, ::4, 0, 0],
+    "encoder.backbone.12.conv.2.weight": np.s_[::2, ::8, 0, 0], "encoder.backbone.10.conv.2.weight": np.s_[::2, ::8, 0, 0],
+    "encoder.backbone.10.conv.1.1.weight": np.s_[:], "encoder.backbone.12.conv.3.weight": np.s_[:],
+    "encoder.projection.0.weight": np.s_[::4, ::16], "decoder.attention.weight": np.s_[::4, ::4],
+    "decoder.lstm.weight_hh_l0": np.s_[::16, ::4], "decoder.lstm.weight_ih_l0": np.s_[::16, ::4],
+    "decoder.embedding.weight": np.s_[::40, ::4], "decoder.output_projection.weight": np.s_[::40, ::4],
+}
