@@ -32,12 +32,15 @@ PEAK_BF16_MFMA_TF = 2516.0      # same guide: ~2.5 PF dense bf16 (v_mfma_f32_32x
 GFLOP_TEACHER, GFLOP_STUDENT = 9.80, 18.61
 
 
-def mfma_peak(precision: str, gflop_student: float = GFLOP_STUDENT):
+def mfma_peak(precision: str, gflop_student: float = GFLOP_STUDENT, teacher_precision: str = "f32"):
     """Roofline denominator for the step: the teacher always runs on the fp32 MFMA; the student's contractions run on
     the fp32 MFMA ("f32"), on the bf16 MFMA ("bf16") or as 3 bf16 MFMAs per product ("bf16x3").  The blended peak
     is total FLOPs / (time of each part at its own MFMA peak)."""
-    ps = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "fp16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 3}[precision]
-    return (GFLOP_TEACHER + gflop_student) / (GFLOP_TEACHER / PEAK_F32_MFMA_TF + gflop_student / ps)
+    ps = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "fp16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 3, "f32x3": None}[precision]
+    pt = PEAK_F32_MFMA_TF if teacher_precision == "f32" else PEAK_BF16_MFMA_TF / 3     # "f32x3": three fp16 MFMAs per product
+    if precision == "f32x3":      # forward products (8.73 GFLOP/image, SURVEY 8d) as three fp16 MFMAs, every gradient launch exact fp32
+        return (GFLOP_TEACHER + gflop_student) / (GFLOP_TEACHER / pt + 8.73 / (PEAK_BF16_MFMA_TF / 3) + (gflop_student - 8.73) / PEAK_F32_MFMA_TF)
+    return (GFLOP_TEACHER + gflop_student) / (GFLOP_TEACHER / pt + gflop_student / ps)
 BATCH = 64
 VOCAB, T1 = 5000, 16
 
@@ -148,7 +151,7 @@ def cpu_baseline(batch: int = BATCH, budget_s: float = 20.0):
                       f"AdamW) timed separately over {len(t_opt)} steps; torch {torch.__version__} CPU eager"}
 
 
-def run_kd(args, precision, dev, rank, world, log, student_cfg=None, batch=None):
+def run_kd(args, precision, dev, rank, world, log, student_cfg=None, batch=None, teacher_precision=None):
     """W untimed + K timed KD train steps (hipGraph replays) at the given student precision.  Returns
     (images/s whole job, wall seconds for K steps [max over ranks], device ms for K steps on this rank, loss dict).
     student_cfg / batch default to the command line's (the extras pass cfg5 / 32)."""
@@ -161,7 +164,8 @@ def run_kd(args, precision, dev, rank, world, log, student_cfg=None, batch=None)
     dims = dict(embed_size=384, hidden_size=768, num_layers=3) if student_cfg == "cfg5" else {}
     student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev, **dims)   # identical init on every rank
     trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
-                        use_graph=not args.no_graph, precision=precision, overlap_teacher=not args.no_overlap)
+                        use_graph=not args.no_graph, precision=precision, overlap_teacher=not args.no_overlap,
+                        teacher_precision=teacher_precision or args.teacher_precision)
     images, caps = synthetic_batch(args.batch, VOCAB, T1, seed=1234, rank=rank)     # rank-specific shard of the global batch
     log(f"[{precision}] models built; first step (hipGraph capture) ...")
     trainer.train_step(images.to(dev), caps.to(dev))                                # inputs resident in HBM from here on
@@ -329,6 +333,8 @@ def main():
                     help="only time the dominant kernel in isolation (for the matching rocprofv3 --kernel-trace --stats run)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (bf16 step, cfg2 decode) at N=1")
     ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream instead of a parallel graph branch")
+    ap.add_argument("--teacher-precision", default="f32", choices=["f32", "f32x3"],
+                    help="teacher Linear arithmetic: exact fp32 MFMA (default, the headline's regime) or fp32-grade three-fp16-product GEMMs")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "fp16", "bf16x3"],
                     help="student/projector GEMM arithmetic (teacher stays fp32 as in the reference); f32 = parity regime")
     args = ap.parse_args()
@@ -378,7 +384,7 @@ def main():
         gflop_img = GFLOP_PER_IMAGE if args.student == "cfg3" else 30.7   # cfg5 = 30.7 algorithmic GFLOP/image
         achieved = gflop_img * args.batch / step_ms_dev                   # GFLOP / ms = TFLOP/s, this rank's GPU
         traffic, traffic_src = measured_traffic(args.batch, args.precision)
-        peak = mfma_peak(args.precision, gflop_img - GFLOP_TEACHER)
+        peak = mfma_peak(args.precision, gflop_img - GFLOP_TEACHER, teacher_precision=args.teacher_precision)
         dtype = {"f32": "f32", "bf16": "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher",
                  "fp16": "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler) + f32 teacher",
                  "bf16x3": "split-bf16x3 student + f32 teacher"}[args.precision]
@@ -406,14 +412,18 @@ def main():
             if args.precision == "f32":
                 # the reference's AMP regime (train_student_kd.py:239,271: fp16 autocast + GradScaler), then its bf16 twin
                 out["mixed_precision"] = {}
-                for prec2, label in (("fp16", "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler 2^16) + f32 teacher"),
-                                     ("bf16", "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher")):
-                    ips2, dt2, dev2, loss2 = run_kd(args, prec2, dev, rank, world, log)
+                for key2, prec2, tprec2, label in (
+                        ("fp16", "fp16", "f32", "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler 2^16) + f32 teacher"),
+                        ("bf16", "bf16", "f32", "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher"),
+                        ("f32_teacher_f32x3", "f32", "f32x3", "f32 student (exact fp32 MFMA) + teacher Linears as fp32-grade three-fp16-product GEMMs (igemm_glds_impl.h TERMS 4; error vs float64 = the exact-fp32 kernel's)"),
+                        ("f32x3", "f32x3", "f32x3", "fp32-grade step: every FORWARD Linear / convolution of teacher and student as three fp16 MFMAs per product, every gradient launch exact fp32 MFMA (tests/test_kd_step_b16_gpu.py[f32x3]: same fp64 yardstick as the exact path)"),
+                        ("fp16_teacher_f32x3", "fp16", "f32x3", "fp16 student as above + teacher Linears as fp32-grade three-fp16-product GEMMs")):
+                    ips2, dt2, dev2, loss2 = run_kd(args, prec2, dev, rank, world, log, teacher_precision=tprec2)
                     ach2 = GFLOP_PER_IMAGE * args.batch / (dev2 / args.steps)
-                    out["mixed_precision"][prec2] = {"dtype": label, "value": round(ips2, 2), "unit": "images/s",
+                    out["mixed_precision"][key2] = {"dtype": label, "value": round(ips2, 2), "unit": "images/s",
                                                      "ms_per_step": round(dt2 / args.steps * 1e3, 3),
                                                      "final_loss": round(loss2["total_loss"], 5), "achieved_TFLOPs": round(ach2, 2),
-                                                     "blended_peak_TFLOPs": round(mfma_peak(prec2), 1)}
+                                                     "blended_peak_TFLOPs": round(mfma_peak(prec2, teacher_precision=tprec2), 1)}
             out["cfg2"] = run_cfg2(dev, log)
             # cfg5's per-rank workload (large student 384/768/3 + teacher, per-GPU batch 32 of the 8-GPU global batch 256),
             # 30.7 algorithmic GFLOP/image, and its "beam=5 eval"

@@ -638,9 +638,17 @@ int run_regs_h16(const IckGemm* d, int fp16, const P& p, int nz, hipStream_t st)
 
 extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
   using namespace ickg;
-  ICK_REQUIRE(terms >= 1 && terms <= 3, "ick_gemm_bf16: terms must be 1 (bf16), 2 (fp16) or 3 (split bf16), got %d", terms);
+  ICK_REQUIRE(terms >= 1 && terms <= 4, "ick_gemm_bf16: terms must be 1 (bf16), 2 (fp16), 3 (split bf16) or 4 (fp32 by three fp16 products), got %d", terms);
   ICK_REQUIRE(d != nullptr, "ick_gemm_bf16: null descriptor");
-  ICK_REQUIRE(d->io16 == 0 || terms != 3, "ick_gemm_bf16: a 16-bit C / residual needs terms 1 (bf16) or 2 (fp16)");
+  ICK_REQUIRE(d->io16 == 0 || terms < 3, "ick_gemm_bf16: a 16-bit C / residual needs terms 1 (bf16) or 2 (fp16)");
+  if (terms == 4) {   // fp32-grade results: the three-product kernel where it exists (k-contiguous forward products), exact fp32 MFMA elsewhere
+    const bool fwd = (d->op == ICK_OP_NT || d->op == ICK_OP_CONV_FWD) && !(d->tile & 256) && glds_eligible(d);
+    if (!fwd) return ick_gemm_f32(d, stream);
+    P p4; int nz4 = 1;
+    if (int rc = prepare(d, BK, p4, nz4, "ick_gemm_bf16")) return rc;
+    IckGemm d4 = *d; d4.tile &= 255;
+    return run_glds_bf16(&d4, 4, p4, nz4, static_cast<hipStream_t>(stream));
+  }
   P p; int nz = 1;
   if (int rc = prepare(d, BK, p, nz, "ick_gemm_bf16")) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);

@@ -8,6 +8,13 @@
 //   TERMS 1  bf16             v_mfma_f32_32x32x16_bf16: two ds_read_b128 = 8 consecutive k per lane, rounded to bf16 IN
 //   TERMS 2  fp16             v_mfma_f32_32x32x16_f16   REGISTERS (the LDS images stay fp32: operands are fp32 in HBM)
 //   TERMS 3  split bf16       hi + lo parts in registers, hi*hi + hi*lo + lo*hi (~1e-5 of the fp32 product)
+//   TERMS 4  fp32 BY THREE fp16 PRODUCTS ("f32x3"; round 3, NT / CONV_FWD only): a = hi + 2^-11 lo', hi = fp16(a),
+//                              lo' = fp16(2^11 (a - hi)) — 22-23 of a's 24 significand bits; hi*hi goes to one accumulator,
+//                              hi*lo' + lo'*hi to a second one that is folded in with 2^-11 after the k-loop (the scaling
+//                              keeps lo' out of fp16's subnormal range; only lo*lo, <= 2^-22 of the product, is dropped).
+//                              3 MFMAs of 32 cycles per 16 k against 8 of 64 for TERMS 0; measured error against float64
+//                              on the ViT shapes = that of TERMS 0 (tests/test_gemm_gpu.py).  Operands must be < 65504 in
+//                              magnitude (fp16's range: larger values give inf — loud, not silent).
 //   TERMS 5 / 6  NATIVE bf16 / fp16 operands: A and B are 16-bit in HBM and in LDS.  The kernel addresses them in
 //                              "units" of two halves (the host halves K, lda, ldb, Cin), so every line of addressing / DMA /
 //                              swizzle code is the fp32 one; the fp32-style fragment (ds_read_b128 = 4 units) IS the 8
@@ -49,11 +56,12 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 template <int TERMS> struct Half16 { using x8 = bf16x8; using x4 = bf16x4; };
+template <> struct Half16<4> { using x8 = f16x8; using x4 = f16x4; };
 template <> struct Half16<2> { using x8 = f16x8; using x4 = f16x4; };   // fp16: 10 mantissa bits, 5-bit exponent — run under the device GradScaler
 template <> struct Half16<6> { using x8 = f16x8; using x4 = f16x4; };
 template <int TERMS, typename V>
 __device__ __forceinline__ f32x16 mfma16(V a, V b, f32x16 c) {
-  if constexpr (TERMS == 2 || TERMS == 6) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  if constexpr (TERMS == 2 || TERMS == 4 || TERMS == 6) return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
@@ -134,7 +142,7 @@ void igemm_glds_kernel(const P p) {
   constexpr int A_TPK = X16 ? BM / 8 : BM / 4, B_TPK = X16 ? BN / 8 : BN / 4;   // lanes per k-row of an x-contiguous image
   constexpr int A_RPI = 64 / A_TPK, B_RPI = 64 / B_TPK;  // k-rows per DMA instruction (x-contiguous)
   constexpr int A_NG = X16 ? BM / 32 : 1, B_NG = X16 ? BN / 32 : 1;             // 64-byte granules per image row (X16)
-  constexpr bool H16OUT = TERMS != 0 && TERMS != 3;       // variants that can write C / read the residual as 16-bit (P.c16 / P.r16)
+  constexpr bool H16OUT = TERMS != 0 && TERMS != 3 && TERMS != 4;       // variants that can write C / read the residual as 16-bit (P.c16 / P.r16)
 
   __shared__ __attribute__((aligned(16))) float lds[NBUF * BUF];
 
@@ -587,11 +595,13 @@ void igemm_glds_kernel(const P p) {
         for (int i = 0; i < TM; ++i) {
           ah[i] = __builtin_convertvector(av[cur][i], h8);
           if constexpr (TERMS == 3) al[i] = __builtin_convertvector(av[cur][i] - __builtin_convertvector(ah[i], f32x8), h8);
+          if constexpr (TERMS == 4) al[i] = __builtin_convertvector((av[cur][i] - __builtin_convertvector(ah[i], f32x8)) * 2048.f, h8);
         }
 #pragma unroll
         for (int t = 0; t < TN; ++t) {
           bh[t] = __builtin_convertvector(bv[cur][t], h8);
           if constexpr (TERMS == 3) bl[t] = __builtin_convertvector(bv[cur][t] - __builtin_convertvector(bh[t], f32x8), h8);
+          if constexpr (TERMS == 4) bl[t] = __builtin_convertvector((bv[cur][t] - __builtin_convertvector(bh[t], f32x8)) * 2048.f, h8);
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -600,6 +610,10 @@ void igemm_glds_kernel(const P p) {
             if constexpr (TERMS == 3) {   // small terms first
               acc[i][t] = mfma16<TERMS>(al[i], bh[t], acc[i][t]);
               acc[i][t] = mfma16<TERMS>(ah[i], bl[t], acc[i][t]);
+            }
+            if constexpr (TERMS == 4) {   // the cross terms, scaled by 2^11, in their own accumulator
+              tot[i][t] = mfma16<TERMS>(al[i], bh[t], tot[i][t]);
+              tot[i][t] = mfma16<TERMS>(ah[i], bl[t], tot[i][t]);
             }
             acc[i][t] = mfma16<TERMS>(ah[i], bh[t], acc[i][t]);
           }
@@ -623,6 +637,12 @@ void igemm_glds_kernel(const P p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t];
+  }
+  if constexpr (TERMS == 4) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t] * (1.f / 2048.f);
   }
   if constexpr (IL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last k-tiles' zero-page pieces must land before the buffers become the C slab
   stamp(2, true);
@@ -895,6 +915,10 @@ int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
     if (d->op == ICK_OP_TN) return dispatch_tile<ICK_OP_TN, TERMS>(p, nz, st, d->tile);               // x-contiguous operands (X16)
     if (d->op == ICK_OP_CONV_WGRAD) return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS>(p, nz, st, d->tile);
     return ick::fail(-1, "igemm (native 16-bit, LDS-DMA): NT, CONV_FWD, TN and CONV_WGRAD only, got op %d", d->op);
+  } else if constexpr (TERMS == 4) {   // the frozen teacher's forward products only
+    if (d->op == ICK_OP_NT) return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
+    if (d->op == ICK_OP_CONV_FWD) return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
+    return ick::fail(-1, "igemm (f32x3, LDS-DMA): NT and CONV_FWD only, got op %d", d->op);
   } else
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);

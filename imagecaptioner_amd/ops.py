@@ -66,6 +66,7 @@ def _load_tuned(name: str = "tuned_tiles.json"):
 
 
 _TUNED = _load_tuned()
+_TUNED_X3 = _load_tuned("tuned_tiles_f32x3.json")       # same keys, for the f32x3 (three fp16 products) forward kernels
 _TUNED_BF16 = _load_tuned("tuned_tiles_bf16.json")     # same keys, for the bf16 / bf16x3 kernel family
 _TUNED_H16 = _load_tuned("tuned_tiles_h16.json")       # same keys, for the native 16-bit operand kernels (ick_gemm_h16)
 _H16 = (torch.bfloat16, torch.float16)
@@ -86,7 +87,10 @@ def _io16(c: torch.Tensor, residual: Optional[torch.Tensor], h16) -> int:
 # Arithmetic of every dense contraction (Linear / attention products / convolutions): "f32" = exact fp32 MFMA (the
 # parity regime), "bf16" = bf16 MFMA with fp32 accumulation (the reference's autocast regime, train_student_kd.py:263),
 # "bf16x3" = split-bf16 (hi*hi + hi*lo + lo*hi, ~1e-5 of fp32).  Operands stay fp32 in HBM in all three.
-_PRECISIONS = {"f32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3}     # "fp16": fp16 MFMA products (the reference's autocast dtype)
+# "f32x3" = fp32-grade products from three fp16 MFMAs (igemm_glds_impl.h TERMS 4: a = hi + 2^-11 lo', error against float64 equal
+# to the exact-fp32 kernel's) for k-contiguous FORWARD products (Linear / convolution forward: call sites that pass x3=True to
+# gemm_raw); every other launch — all gradients — runs the exact-fp32 kernel.
+_PRECISIONS = {"f32": 0, "bf16": 1, "fp16": 2, "bf16x3": 3, "f32x3": 4}     # "fp16": fp16 MFMA products (the reference's autocast dtype)
 _PREC = ["f32"]
 
 
@@ -123,9 +127,11 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
              accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
              conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0,
              col_scale: Optional[int] = None, kchunk: int = 0, h16: Optional[torch.dtype] = None, io16: int = 0,
-             default_tile: int = 0) -> None:
+             default_tile: int = 0, x3: bool = False) -> None:
     """h16 = torch.bfloat16 / torch.float16: A and B hold that type in HBM (ick_gemm_h16); io16 bit 0 / 1: so do C / the
-    residual."""
+    residual.  x3: the call site states that both operands are FORWARD quantities (activations, weights: magnitudes inside
+    fp16's normal range) — only such launches take the three-fp16-product kernel under precision "f32x3"; gradients, whose
+    magnitudes can sit below fp16's 6e-5, always take the exact-fp32 kernel there."""
     d = IckGemm()
     d.A, d.B, d.C = A, B, C
     d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
@@ -146,7 +152,13 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
         check(_lib.lib().ick_gemm_h16(ctypes.byref(d), int(h16 == torch.float16), _st()), "ick_gemm_h16")
         return
     terms = _PRECISIONS[_PREC[0]]
+    if terms == 4 and not (x3 and op in (OP_NT, OP_CONV_FWD)):
+        terms = 0
     d.io16 = io16        # (fp32 operands: only the bf16 / fp16 LDS-DMA variants can write a 16-bit C; the others refuse)
+    if terms == 4:
+        d.tile = tile or _FORCE_TILE[0] or _TUNED_X3.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
+        check(_lib.lib().ick_gemm_bf16(ctypes.byref(d), terms, _st()), "ick_gemm_bf16")
+        return
     if terms:
         d.tile = tile or _FORCE_TILE[0] or _TUNED_BF16.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
         check(_lib.lib().ick_gemm_bf16(ctypes.byref(d), terms, _st()), "ick_gemm_bf16")
@@ -186,7 +198,7 @@ def linear_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = 
     assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
     y = out if out is not None else empty(*x.shape[:-1], N, device=x.device)
     gemm_raw(OP_NT, x.data_ptr(), w.data_ptr(), y.data_ptr(), M, N, K, K, K, N, bias=_ptr(bias),
-             residual=_ptr(residual), ldr=N, act=act)
+             residual=_ptr(residual), ldr=N, act=act, x3=True)
     return y
 
 
@@ -401,22 +413,22 @@ def conv_fwd(x: torch.Tensor, w: torch.Tensor, stride: int, pad: int, stats: Opt
         gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout, bias=shift.data_ptr(),
                  col_scale=scale.data_ptr(), residual=_ptr(residual), ldr=Cout,
                  act=(ACT_RELU if relu else ACT_NONE) | _lib.ACT_POST_RESIDUAL,
-                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+                 conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), x3=True)
         return y
-    sk = _conv_splitk(Nb * Ho * Wo, Cout, K) if (stats is not None and op == OP_CONV_FWD and _PREC[0] == "f32") else 1
+    sk = _conv_splitk(Nb * Ho * Wo, Cout, K) if (stats is not None and op == OP_CONV_FWD and _PREC[0] in ("f32", "f32x3")) else 1
     if sk > 1:
         # train-mode forward on a small grid: split the contraction (fp32 atomics into the zeroed output), then take the
         # BatchNorm statistics from the finished output in one pass over its 6 MB (the epilogue cannot: it sees partial sums)
         y.zero_()
         gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout, splitk=sk,
-                 default_tile=4 if K >= 4096 else 2, conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+                 default_tile=4 if K >= 4096 else 2, conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), x3=True)
         s0, s1 = (stats[0][0], stats[1][0]) if stats[0].dim() == 2 else (stats[0], stats[1])
         check(_lib.lib().ick_colstats(y.data_ptr(), s0.data_ptr(), s1.data_ptr(), Nb * Ho * Wo, Cout, _st()), "ick_colstats")
         return y
     gemm_raw(op, x.data_ptr(), w.data_ptr(), y.data_ptr(), Nb * Ho * Wo, Cout, K, K, K, Cout,
              stat_sum=_ptr(stats[0]) if stats is not None else None, stat_sq=_ptr(stats[1]) if stats is not None else None,
              stat_copies=stats[0].shape[0] if (stats is not None and stats[0].dim() == 2) else 1, stat_stride=Cout,
-             conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad))
+             conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), x3=True)
     return y
 
 
@@ -873,10 +885,10 @@ def gemm_nt(x: torch.Tensor, w_ptr: int, N: int, K: int, ldb: int, out: torch.Te
         if not accumulate and not zeroed:
             out.zero_()
         gemm_raw(OP_NT, x.data_ptr(), w_ptr, out.data_ptr(), M, N, K, K, ldb, N, bias=_ptr(bias), residual=_ptr(residual),
-                 ldr=N, splitk=splitk)
+                 ldr=N, splitk=splitk, x3=True)
     else:
         gemm_raw(OP_NT, x.data_ptr(), w_ptr, out.data_ptr(), M, N, K, K, ldb, N, bias=_ptr(bias), residual=_ptr(residual),
-                 ldr=N, act=act, accumulate=accumulate)
+                 ldr=N, act=act, accumulate=accumulate, x3=True)
     return out
 
 

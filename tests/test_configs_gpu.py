@@ -514,3 +514,38 @@ def test_cfg5_step_properties_at_its_per_gpu_batch():
     assert a[-1] < a[0] and b[-1] < b[0]
     assert abs(a[0] - b[0]) <= 1e-4 * abs(a[0])
     assert abs(a[-1] - b[-1]) <= 2e-2 * abs(a[-1])
+
+
+def test_teacher_f32x3_step_equals_exact_fp32_teacher_step():
+    """KDTrainer(teacher_precision="f32x3") — the frozen teacher's Linears as three fp16 MFMAs per product with a scaled low part
+    (fp32-grade: tests/test_gemm_gpu.py::test_f32x3_is_fp32_grade) — against the exact-fp32 teacher at the metric's batch: the
+    teacher logits the two regimes distil from agree to 2e-5 of their scale, every loss term to 1e-5 relative, the gradient
+    norm to 1e-4 (north_star's bound is 1e-3 on logits and loss terms)."""
+    from imagecaptioner_amd import ops
+    from imagecaptioner_amd.distillation_utils import TeacherWrapper
+    from imagecaptioner_amd.train_student_kd import KDTrainer, build_kd_models
+    from imagecaptioner_amd.utils.seeded_init import synthetic_batch
+    images, caps = synthetic_batch(64, 5000, 16, seed=1234)
+    images, caps = images.cuda(), caps.cuda()
+    res = {}
+    for tp in ("f32", "f32x3"):
+        student, teacher, projectors = build_kd_models(device="cuda")
+        for m in list(student.modules()) + list(projectors["encoder"].modules()):
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
+        student.attention_refinement.attention.dropout = 0.0
+        student.decoder.lstm.dropout = 0.0
+        with ops.precision(tp):
+            tl = TeacherWrapper(teacher)(images, caps[:-1])["logits"].clone()
+        tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=64, t_plus_1=16, use_graph=True, teacher_precision=tp)
+        tr.train_step(images, caps)
+        torch.cuda.synchronize()
+        res[tp] = (tl, tr.loss_dict(), float(tr.grad_norm()) if hasattr(tr, "grad_norm") else None)
+        tr.close()
+    a, b = res["f32"], res["f32x3"]
+    assert ((a[0] - b[0]).abs().max() / a[0].abs().max()).item() < 2e-5
+    assert not torch.equal(a[0], b[0])                     # the three-product kernel did run
+    for k in a[1]:
+        assert abs(a[1][k] - b[1][k]) <= 1e-5 * max(1.0, abs(a[1][k])), (k, a[1][k], b[1][k])
+    if a[2] is not None:
+        assert abs(a[2] - b[2]) <= 1e-4 * a[2]

@@ -201,16 +201,22 @@ def test_cfg1_student_eval_and_greedy():
     assert words == [V.itos[int(i)] for i in ref[:n0, 0]]
 
 
-def test_teacher_eval():
+@pytest.mark.parametrize("teacher_precision", ["f32", "f32x3"])
+def test_teacher_eval(teacher_precision):
+    """"f32x3": the teacher's Linears as fp32-grade three-fp16-product GEMMs (igemm_glds_impl.h TERMS 4) — held to the SAME
+    tolerances against the reference's golden as the exact-fp32 path, argmax ids bit-exact included."""
+    from imagecaptioner_amd import ops
     from imagecaptioner_amd.distillation_utils import TeacherWrapper
     from imagecaptioner_amd.teacher_model import CaptioningTeacher
     from imagecaptioner_amd.utils.seeded_init import synthetic_batch
     g = load_golden("teacher_eval.npz")
     tm = seeded(CaptioningTeacher(5000, embed_size=512, num_heads=8, num_decoder_layers=4, dropout=0.15), 1).cuda()
     images, caps = synthetic_batch(2, 5000, 16, seed=1234)
-    out = TeacherWrapper(tm)(images.cuda(), caps[:-1].cuda())
+    with ops.precision(teacher_precision):
+        out = TeacherWrapper(tm)(images.cuda(), caps[:-1].cuda())
+        vit = tm.encoder.forward_features(images.cuda())
     assert out["hidden_states"] is None and not any(p.requires_grad for p in tm.parameters())
-    close(tm.encoder.forward_features(images.cuda())[:, ::4], g["vit_tokens"], name="vit tokens")
+    close(vit[:, ::4], g["vit_tokens"], name="vit tokens")
     close(out["encoder_features"][:, ::4], g["enc_feats"], name="enc_feats")
     close(out["logits"], g["logits"], name="logits")
     assert (out["logits"].cpu() - t(g["logits"])).abs().max().item() < 1e-3

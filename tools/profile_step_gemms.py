@@ -26,7 +26,8 @@ orig = ops.gemm_raw
 
 
 def rec(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw):
-    if (ops.gemm_precision() == "f32") != (PREC == "f32") or (kw.get("h16") is not None) != (H16 is not None):
+    if (ops.gemm_precision() == "f32") != (PREC == "f32") or (kw.get("h16") is not None) != (H16 is not None) or \
+            (PREC == "f32x3" and not (kw.get("x3") and op in (0, 3))):
         return orig(op, A, Bp, C, M, N, K, lda, ldb, ldc, **kw)          # AMP: only the student's 16-bit launches are swept
     records.append((op, M, N, K, lda, ldb, ldc, kw.get("batch", (1, 1)), kw.get("strides", (0,) * 6), kw.get("splitk", 1),
                     kw.get("conv"), kw.get("act", 0), kw.get("bias") is not None, kw.get("residual") is not None,
@@ -52,9 +53,10 @@ if WORKLOAD == "cfg2":
 else:
     dims = dict(embed_size=384, hidden_size=768, num_layers=3) if WORKLOAD == "cfg5" else {}
     student, teacher, projectors = build_kd_models(device="cuda", **dims)
-    tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=B, use_graph=False, precision=PREC, overlap_teacher=False)
+    tr = KDTrainer(student, teacher, projectors, vocab_size=5000, batch_size=B, use_graph=False, overlap_teacher=False,
+                   precision=PREC, teacher_precision="f32x3" if PREC == "f32x3" else "f32")   # "f32x3": the forward launches of teacher and student
     if PREC != "f32":
-        ops._TUNED_BF16.clear(); ops._TUNED_H16.clear()
+        ops._TUNED_BF16.clear(); ops._TUNED_H16.clear(); ops._TUNED_X3.clear()
     images, caps = synthetic_batch(B, 5000, 16)
     tr.train_step(images.cuda(), caps.cuda())
     ops.gemm_raw = rec
@@ -92,6 +94,8 @@ def timeit(f, iters=10):
 for r, n in cnt.items():
     op, M, N, K, lda, ldb, ldc, batch, strides, splitk, conv, act, bias, res, st, acc, ldr, io16, scopies, sstride = r
     kw = dict(batch=batch, strides=strides, splitk=splitk, conv=conv, act=act, accumulate=acc, ldr=ldr)
+    if PREC == "f32x3":
+        kw["x3"] = True
     if H16 is not None:
         kw.update(h16=H16, io16=io16)
     if bias:
@@ -107,6 +111,9 @@ for r, n in cnt.items():
     for tile in TILES:
         if tile == 129 and (PREC != "f32" or op not in (0, 3)):
             ts.append(float("inf"))          # loader-wave variant: exact-fp32 NT / CONV_FWD only
+            continue
+        if PREC == "f32x3" and tile > 255:
+            ts.append(float("inf"))          # three-product kernel: the LDS-DMA forward tiles only (everything else IS the exact-fp32 launch)
             continue
         if H16 is not None and ((not kc and (tile > 4)) or (tile & 32)):
             ts.append(float("inf"))          # register-staged kernel only: the four plain tiles
