@@ -165,7 +165,7 @@ def run_kd(args, precision, dev, rank, world, log, student_cfg=None, batch=None,
     student, teacher, projectors = build_kd_models(vocab_size=VOCAB, device=dev, **dims)   # identical init on every rank
     trainer = KDTrainer(student, teacher, projectors, vocab_size=VOCAB, batch_size=args.batch, t_plus_1=T1,
                         use_graph=not args.no_graph, precision=precision, overlap_teacher=not args.no_overlap,
-                        teacher_precision=teacher_precision or args.teacher_precision)
+                        teacher_precision=teacher_precision or args.teacher_precision or ("f32" if precision == "f32" else "f32x3"))
     images, caps = synthetic_batch(args.batch, VOCAB, T1, seed=1234, rank=rank)     # rank-specific shard of the global batch
     log(f"[{precision}] models built; first step (hipGraph capture) ...")
     trainer.train_step(images.to(dev), caps.to(dev))                                # inputs resident in HBM from here on
@@ -263,6 +263,15 @@ def run_beam_eval(dev, log, batch=64, beam=5, max_length=20, iters=3):
         caps = t.caption_images(images, vocab, max_length=max_length, beam_size=beam)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    from imagecaptioner_amd import ops
+    with ops.precision("f32x3"):           # the same search with every Linear as three fp16 MFMAs per product (fp32-grade)
+        caps3 = t.caption_images(images, vocab, max_length=max_length, beam_size=beam)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(iters):
+            caps3 = t.caption_images(images, vocab, max_length=max_length, beam_size=beam)
+        torch.cuda.synchronize()
+        dt3 = (time.perf_counter() - t3) / iters
     t.caption_image_recompute(images[0], vocab, max_length=max_length, beam_size=beam)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
@@ -275,7 +284,9 @@ def run_beam_eval(dev, log, batch=64, beam=5, max_length=20, iters=3):
            "dtype": "f32", "images_per_s": round(batch / dt, 1), "beam_tokens_per_s": round(batch * beam * max_length / dt, 1),
            "ms_per_batch": round(dt * 1e3, 2),
            "prefix_rerun_one_image_at_a_time_images_per_s": round(1.0 / dt_ref, 2), "speedup_vs_prefix_rerun": round(dt_ref * batch / dt, 1),
-           "mean_caption_words": round(sum(len(c[0].split()) for c in caps) / len(caps), 2)}
+           "mean_caption_words": round(sum(len(c[0].split()) for c in caps) / len(caps), 2),
+           "f32x3": {"images_per_s": round(batch / dt3, 1), "ms_per_batch": round(dt3 * 1e3, 2),
+                     "captions_identical_to_f32": sum(a == b for a, b in zip(caps, caps3)), "of": len(caps)}}
     del t
     torch.cuda.empty_cache()
     return out
@@ -333,9 +344,10 @@ def main():
                     help="only time the dominant kernel in isolation (for the matching rocprofv3 --kernel-trace --stats run)")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (bf16 step, cfg2 decode) at N=1")
     ap.add_argument("--no-overlap", action="store_true", help="teacher forward on the main stream instead of a parallel graph branch")
-    ap.add_argument("--teacher-precision", default="f32", choices=["f32", "f32x3"],
-                    help="teacher Linear arithmetic: exact fp32 MFMA (default, the headline's regime) or fp32-grade three-fp16-product GEMMs")
-    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "fp16", "bf16x3"],
+    ap.add_argument("--teacher-precision", default=None, choices=["f32", "f32x3"],
+                    help="teacher Linear arithmetic: exact fp32 MFMA (default with --precision f32, the headline's regime) or fp32-grade "
+                         "three-fp16-product GEMMs (default otherwise)")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16", "fp16", "bf16x3", "f32x3"],
                     help="student/projector GEMM arithmetic (teacher stays fp32 as in the reference); f32 = parity regime")
     args = ap.parse_args()
 
@@ -384,10 +396,12 @@ def main():
         gflop_img = GFLOP_PER_IMAGE if args.student == "cfg3" else 30.7   # cfg5 = 30.7 algorithmic GFLOP/image
         achieved = gflop_img * args.batch / step_ms_dev                   # GFLOP / ms = TFLOP/s, this rank's GPU
         traffic, traffic_src = measured_traffic(args.batch, args.precision)
-        peak = mfma_peak(args.precision, gflop_img - GFLOP_TEACHER, teacher_precision=args.teacher_precision)
+        tprec = args.teacher_precision or ("f32" if args.precision == "f32" else "f32x3")
+        peak = mfma_peak(args.precision, gflop_img - GFLOP_TEACHER, teacher_precision=tprec)
         dtype = {"f32": "f32", "bf16": "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher",
                  "fp16": "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler) + f32 teacher",
-                 "bf16x3": "split-bf16x3 student + f32 teacher"}[args.precision]
+                 "bf16x3": "split-bf16x3 student + f32 teacher",
+                 "f32x3": "f32-grade: forward Linears / convolutions as three fp16 MFMAs per product, gradients exact fp32 MFMA"}[args.precision]
         out = {
             "metric": "images/sec KD train step (teacher+student fwd + KD loss + bwd)", "value": round(ips, 2),
             "unit": "images/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
@@ -412,12 +426,15 @@ def main():
             if args.precision == "f32":
                 # the reference's AMP regime (train_student_kd.py:239,271: fp16 autocast + GradScaler), then its bf16 twin
                 out["mixed_precision"] = {}
+                X3 = "teacher Linears fp32-GRADE from three fp16 MFMAs per product (igemm_glds_impl.h TERMS 4: error vs float64 = the exact-fp32 kernel's)"
+                S16 = "student on 16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights"
                 for key2, prec2, tprec2, label in (
-                        ("fp16", "fp16", "f32", "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler 2^16) + f32 teacher"),
-                        ("bf16", "bf16", "f32", "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher"),
-                        ("f32_teacher_f32x3", "f32", "f32x3", "f32 student (exact fp32 MFMA) + teacher Linears as fp32-grade three-fp16-product GEMMs (igemm_glds_impl.h TERMS 4; error vs float64 = the exact-fp32 kernel's)"),
-                        ("f32x3", "f32x3", "f32x3", "fp32-grade step: every FORWARD Linear / convolution of teacher and student as three fp16 MFMAs per product, every gradient launch exact fp32 MFMA (tests/test_kd_step_b16_gpu.py[f32x3]: same fp64 yardstick as the exact path)"),
-                        ("fp16_teacher_f32x3", "fp16", "f32x3", "fp16 student as above + teacher Linears as fp32-grade three-fp16-product GEMMs")):
+                        ("fp16", "fp16", "f32x3", f"fp16 {S16}, device GradScaler 2^16; {X3} — KDTrainer's default teacher in this regime"),
+                        ("bf16", "bf16", "f32x3", f"bf16 {S16}; {X3}"),
+                        ("fp16_exact_fp32_teacher", "fp16", "f32", f"fp16 {S16}, device GradScaler 2^16; teacher on the exact fp32 MFMA (rounds 1-2's fp16 line)"),
+                        ("f32x3", "f32x3", "f32x3", "fp32-grade step: every FORWARD Linear / convolution of teacher and student as three fp16 MFMAs per product, every gradient "
+                                                    "launch exact fp32 MFMA (tests/test_kd_step_b16_gpu.py[f32x3]: same fp64 yardstick as the exact path)"),
+                        ("f32_teacher_f32x3", "f32", "f32x3", f"student exact fp32 MFMA; {X3}")):
                     ips2, dt2, dev2, loss2 = run_kd(args, prec2, dev, rank, world, log, teacher_precision=tprec2)
                     ach2 = GFLOP_PER_IMAGE * args.batch / (dev2 / args.steps)
                     out["mixed_precision"][key2] = {"dtype": label, "value": round(ips2, 2), "unit": "images/s",
@@ -428,11 +445,11 @@ def main():
             # cfg5's per-rank workload (large student 384/768/3 + teacher, per-GPU batch 32 of the 8-GPU global batch 256),
             # 30.7 algorithmic GFLOP/image, and its "beam=5 eval"
             out["cfg5_per_rank"] = {}
-            for prec5 in ("f32", "fp16"):
+            for prec5 in ("f32", "fp16", "f32x3"):
                 ips5, dt5, dev5, loss5 = run_kd(args, prec5, dev, rank, world, log, student_cfg="cfg5", batch=32)
                 ach5 = 30.7 * 32 / (dev5 / args.steps)
-                pk5 = mfma_peak(prec5, 30.7 - GFLOP_TEACHER)
-                out["cfg5_per_rank"][prec5] = {"workload": "cfg5 KD step: student 384/768/3-layer + ViT teacher, per-GPU batch 32", "value": round(ips5, 2),
+                pk5 = mfma_peak(prec5, 30.7 - GFLOP_TEACHER, teacher_precision="f32" if prec5 == "f32" else "f32x3")
+                out["cfg5_per_rank"][prec5] = {"workload": "cfg5 KD step: student 384/768/3-layer + ViT teacher" + ("" if prec5 == "f32" else " (fp32-grade f32x3 Linears)") + ", per-GPU batch 32", "value": round(ips5, 2),
                                                "unit": "images/s", "ms_per_step": round(dt5 / args.steps * 1e3, 3),
                                                "final_loss": round(loss5["total_loss"], 5), "achieved_TFLOPs": round(ach5, 2),
                                                "peak_TFLOPs": round(pk5, 1), "frac": round(ach5 / pk5, 4)}

@@ -152,6 +152,179 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AP p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same attention with fp32-GRADE products from three fp16 MFMAs each ("f32x3", round 3; igemm_glds_impl.h TERMS 4 has
+// the derivation): x = hi + 2^-11 lo', hi = fp16(x), lo' = fp16(2^11 (x - hi)); hi*hi into one accumulator, hi*lo' + lo'*hi
+// into a second one that is folded in with 2^-11.  v_mfma_f32_32x32x16_f16 multiplies 16 k per 32 cycles where the fp32 MFMA
+// multiplies 2 per 64: a chunk of 32 keys costs 24 MFMAs x 32 cycles per wave instead of 64 x 64.
+//   * K and V are split ONCE, when a chunk is stashed: LDS holds K as two fp16 planes [key][64 d] (pitch 144 B: the four
+//     16-lane groups of a ds_read_b128 hit 16 distinct 16-byte slots) and V TRANSPOSED as two planes [d][32 keys] (pitch
+//     72 B), so that both A fragments are 8 consecutive halves (K: 8 d of one key; V^T: 2 x 4 keys of one d);
+//   * S^T = K Q^T keeps the 32x32 accumulator layout of the fp32 kernel (lane = one query column, 16 of the 32 keys in its
+//     registers), so the online softmax is unchanged;
+//   * O^T += V^T P^T: the B fragment of k-step s is the lane's registers 8s..8s+7, i.e. keys {16s + 4 half + 0..3,
+//     16s + 8 + 4 half + 0..3} — the A fragment reads V^T at exactly those keys (two ds_read_b64), so P never moves
+//     between lanes here either; it is split in registers (probabilities lie in [0, 1]: the range fp16 is best at).
+// Operands must lie in fp16's range (LayerNorm'd activations through a Linear: they do); the host layer calls this entry only
+// under ops.precision("f32x3").
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x8v __attribute__((ext_vector_type(8)));
+constexpr int KHP = 72;     // K plane row pitch in halves (144 B)
+constexpr int VTP = 36;     // V^T plane row pitch in halves (72 B)
+
+__device__ __forceinline__ void split4(const float4 v, f16x4& hi, f16x4& lo) {
+  const f32x4v x = {v.x, v.y, v.z, v.w};
+  hi = __builtin_convertvector(x, f16x4);
+  lo = __builtin_convertvector((x - __builtin_convertvector(hi, f32x4v)) * 2048.f, f16x4);
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(const AP p) {
+  __shared__ __attribute__((aligned(16))) _Float16 Kh[2][KC][KHP], Kl[2][KC][KHP];
+  __shared__ __attribute__((aligned(16))) _Float16 Vh[2][D][VTP], Vl[2][D][VTP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, half = lane >> 5;
+  const int b = blockIdx.x / p.H, h = blockIdx.x - b * p.H;
+  const float* Q = p.q + b * p.qbs + h * D;
+  const float* K = p.k + b * p.kbs + h * D;
+  const float* V = p.v + b * p.vbs + h * D;
+  float* O = p.o + b * p.obs + h * D;
+  const int q0 = (blockIdx.y * NW + wave) * 32;
+  const int qrow = q0 + col;
+  const bool qok = qrow < p.Lq;
+
+  // B operand of S^T = K Q^T, k-step s (16 d): lane (query col, half) supplies d = 16 s + 8 half + 0..7, pre-scaled
+  f16x8 qh[4], ql[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    f32x8v x;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = qok ? Q[(long)qrow * p.qld + 16 * s + 8 * half + j] * p.scale : 0.f;
+    qh[s] = __builtin_convertvector(x, f16x8);
+    ql[s] = __builtin_convertvector((x - __builtin_convertvector(qh[s], f32x8v)) * 2048.f, f16x8);
+  }
+
+  f32x16 ot[2], ox[2];                             // O^T tiles (main / cross-term accumulators)
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { ot[t][r] = 0.f; ox[t][r] = 0.f; }
+  float mrun = -INFINITY, lrun = 0.f;
+
+  constexpr int NTH = NW * 64;
+  constexpr int F4 = KC * D / 4;
+  constexpr int PASS = (F4 + NTH - 1) / NTH;
+  float4 rk[PASS], rv[PASS];
+  const int nchunks = (p.Lk + KC - 1) / KC;
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const int f = tid + i * NTH;
+      const int key = c * KC + f / (D / 4), d4 = (f % (D / 4)) * 4;
+      const bool ok = f < F4 && key < p.Lk;
+      rk[i] = ok ? *reinterpret_cast<const float4*>(K + (long)key * p.kld + d4) : make_float4(0, 0, 0, 0);
+      rv[i] = ok ? *reinterpret_cast<const float4*>(V + (long)key * p.vld + d4) : make_float4(0, 0, 0, 0);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < PASS; ++i) {
+      const int f = tid + i * NTH;
+      if (f < F4) {
+        const int key = f / (D / 4), d4 = (f % (D / 4)) * 4;
+        f16x4 hi, lo;
+        split4(rk[i], hi, lo);
+        *reinterpret_cast<f16x4*>(&Kh[buf][key][d4]) = hi;
+        *reinterpret_cast<f16x4*>(&Kl[buf][key][d4]) = lo;
+        split4(rv[i], hi, lo);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { Vh[buf][d4 + j][key] = hi[j]; Vl[buf][d4 + j][key] = lo[j]; }
+      }
+    }
+  };
+
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunks) fetch(c + 1);
+    // ---- S^T (keys x queries) = K_chunk (32 x 64) . Q^T (64 x 32): 4 k-steps x 3 MFMAs
+    f32x16 st, sx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = 0.f; sx[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f16x8 kh = *reinterpret_cast<const f16x8*>(&Kh[buf][col][16 * s + 8 * half]);
+      const f16x8 kl = *reinterpret_cast<const f16x8*>(&Kl[buf][col][16 * s + 8 * half]);
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[s], sx, 0, 0, 0);
+      sx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[s], sx, 0, 0, 0);
+      st = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[s], st, 0, 0, 0);
+    }
+    // ---- online softmax over this chunk's keys; lane holds keys (r&3) + 8(r>>2) + 4half of column `col`
+    float cmax = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = c * KC + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const bool ok = key < p.Lk && (!p.causal || key <= qrow);
+      st[r] = ok ? st[r] + sx[r] * (1.f / 2048.f) : -INFINITY;
+      cmax = fmaxf(cmax, st[r]);
+    }
+    cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
+    const float mnew = fmaxf(mrun, cmax);
+    const float msafe = mnew == -INFINITY ? 0.f : mnew;
+    const float alpha = expf(mrun - msafe);
+    float csum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - msafe); csum += st[r]; }
+    csum += __shfl_xor(csum, 32);
+    lrun = lrun * alpha + csum;
+    mrun = mnew;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { ot[t][r] *= alpha; ox[t][r] *= alpha; }
+    // ---- O^T (d x queries) += V^T (d x keys) . P^T (keys x queries): 2 k-steps x 2 tiles x 3 MFMAs
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      f32x8v pv;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pv[j] = st[8 * s + j];
+      const f16x8 ph = __builtin_convertvector(pv, f16x8);
+      const f16x8 pl = __builtin_convertvector((pv - __builtin_convertvector(ph, f32x8v)) * 2048.f, f16x8);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const _Float16* vh = &Vh[buf][32 * t + col][16 * s + 4 * half];
+        const _Float16* vl = &Vl[buf][32 * t + col][16 * s + 4 * half];
+        const f16x4 vh0 = *reinterpret_cast<const f16x4*>(vh), vh1 = *reinterpret_cast<const f16x4*>(vh + 8);
+        const f16x4 vl0 = *reinterpret_cast<const f16x4*>(vl), vl1 = *reinterpret_cast<const f16x4*>(vl + 8);
+        const f16x8 vhf = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
+        const f16x8 vlf = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
+        ox[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlf, ph, ox[t], 0, 0, 0);
+        ox[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhf, pl, ox[t], 0, 0, 0);
+        ot[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhf, ph, ot[t], 0, 0, 0);
+      }
+    }
+    if (c + 1 < nchunks) stash(buf ^ 1);
+    __syncthreads();
+  }
+  if (qok) {
+    const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = 32 * t + 8 * g + 4 * half;
+        float o4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o4[j] = (ot[t][4 * g + j] + ox[t][4 * g + j] * (1.f / 2048.f)) * inv;
+        *reinterpret_cast<float4*>(O + (long)qrow * p.old + d0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+      }
+  }
+}
+
 }  // namespace
 
 // q, k, v, o: row matrices; element (b, row, h, c) lives at base + b*bs + row*ld + h*64 + c.
@@ -176,4 +349,21 @@ extern "C" int ick_attention_fwd_d64(const float* q, int64_t qld, int64_t qbs, c
     ICK_LAUNCH((attn_fwd_kernel<1>), dim3(B * H, 1), dim3(64), 0, st, p);
   }
   return ick::launch_status("attention_fwd_d64");
+}
+
+// the same contract, products as three fp16 MFMAs each (fp32-grade; see attn_fwd_x3_kernel)
+extern "C" int ick_attention_fwd_d64_x3(const float* q, int64_t qld, int64_t qbs, const float* k, int64_t kld, int64_t kbs,
+                                        const float* v, int64_t vld, int64_t vbs, float* o, int64_t old, int64_t obs,
+                                        int B, int H, int Lq, int Lk, int causal, float scale, void* stream) {
+  ICK_REQUIRE(q && k && v && o && B > 0 && H > 0 && Lq > 0 && Lk > 0, "ick_attention_fwd_d64_x3: bad arguments");
+  ICK_REQUIRE((kld | vld | old | kbs | vbs | obs) % 4 == 0 && ick::aligned16(k) && ick::aligned16(v) && ick::aligned16(o),
+              "ick_attention_fwd_d64_x3: K/V/O rows must be 16-byte aligned");
+  AP p{q, k, v, o, qld, kld, vld, old, qbs, kbs, vbs, obs, H, Lq, Lk, causal, scale};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int tiles = (Lq + 31) / 32;
+  if (tiles == 7) ICK_LAUNCH((attn_fwd_x3_kernel<7>), dim3(B * H, 1), dim3(448), 0, st, p);
+  else if (tiles >= 4) ICK_LAUNCH((attn_fwd_x3_kernel<4>), dim3(B * H, (tiles + 3) / 4), dim3(256), 0, st, p);
+  else if (tiles >= 2) ICK_LAUNCH((attn_fwd_x3_kernel<2>), dim3(B * H, (tiles + 1) / 2), dim3(128), 0, st, p);
+  else ICK_LAUNCH((attn_fwd_x3_kernel<1>), dim3(B * H, 1), dim3(64), 0, st, p);
+  return ick::launch_status("attention_fwd_d64_x3");
 }

@@ -848,7 +848,7 @@ int launch_tile(const P& p, int nz, hipStream_t st, int tile, int m_begin = 0, i
     case 67: return launch<OP, 128, 64, 2, TERMS, 8>(p, nz, st, m_begin, m_end);
     case 83: return launch<OP, 128, 64, 3, TERMS, 8>(p, nz, st, m_begin, m_end);
     case 129:     // +128: loader waves.  129 = 4 compute + 4 loader waves, three buffers: ONE workgroup per CU (long-K shapes)
-      if constexpr (TERMS == 0 && (OP == ICK_OP_NT || OP == ICK_OP_CONV_FWD)) return launch<OP, 128, 128, 3, TERMS, 4, 4>(p, nz, st, m_begin, m_end);
+      if constexpr ((TERMS == 0 || TERMS == 4) && (OP == ICK_OP_NT || OP == ICK_OP_CONV_FWD)) return launch<OP, 128, 128, 3, TERMS, 4, 4>(p, nz, st, m_begin, m_end);
       else return launch<OP, 128, 128, 2, TERMS>(p, nz, st, m_begin, m_end);
     case 69:      // 256 x 256 x (64 halves), eight waves as 4 x 2 (64 x 128 per wave): large plain GEMMs on native 16-bit operands
       if constexpr (TERMS >= 5 && OP == ICK_OP_NT) return launch<OP, 256, 256, 2, TERMS, 8>(p, nz, st, m_begin, m_end);

@@ -325,9 +325,11 @@ def attention_fwd_fused(q: torch.Tensor, qoff: int, qld: int, k: torch.Tensor, k
     fs = 4
     kbs = Lk * kld if kv_batch_stride is None else kv_batch_stride
     vbs = Lk * vld if kv_batch_stride is None else kv_batch_stride
-    check(_lib.lib().ick_attention_fwd_d64(q.data_ptr() + qoff * fs, qld, Lq * qld, k.data_ptr() + koff * fs, kld, kbs,
-                                           v.data_ptr() + voff * fs, vld, vbs, O.data_ptr(), E, Lq * E, B, H, Lq, Lk,
-                                           int(causal), 1.0 / math.sqrt(d), _st()), "ick_attention_fwd_d64")
+    # under precision "f32x3" the fp32-grade three-fp16-product kernel (forward-only callers: the teacher, eval-mode refinement)
+    fn = _lib.lib().ick_attention_fwd_d64_x3 if _PREC[0] == "f32x3" else _lib.lib().ick_attention_fwd_d64
+    check(fn(q.data_ptr() + qoff * fs, qld, Lq * qld, k.data_ptr() + koff * fs, kld, kbs,
+             v.data_ptr() + voff * fs, vld, vbs, O.data_ptr(), E, Lq * E, B, H, Lq, Lk,
+             int(causal), 1.0 / math.sqrt(d), _st()), "ick_attention_fwd_d64")
     return O
 
 

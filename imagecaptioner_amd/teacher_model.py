@@ -306,7 +306,7 @@ class CaptioningTeacher(nn.Module):
         Same search as the reference (:144-228): only beam 0 is real before the first expansion, `width` candidates survive
         a step, a candidate ending in <END> leaves as a finished hypothesis and narrows that image's beam by one.
         use_graph (default: on, ICK_BEAM_GRAPH=0 switches it off): the ~1000 small launches of the ViT pass + max_length decode
-        steps are captured once per (batch, beam, length, token ids, parameter versions) into a hipGraph and replayed — the
+        steps are captured once per (batch, beam, length, token ids, GEMM precision, parameter versions) into a hipGraph and replayed — the
         search is launch-bound otherwise (320 beam rows per step)."""
         if self.training:
             raise NotImplementedError("the HIP teacher is forward-only/eval")
@@ -315,7 +315,8 @@ class CaptioningTeacher(nn.Module):
         if use_graph is None:
             use_graph = os.environ.get("ICK_BEAM_GRAPH", "1") != "0"
         if use_graph and images.is_cuda:
-            key = (tuple(images.shape), W, max_length, start_id, end_id, tuple((q.data_ptr(), q._version) for q in self.parameters()))
+            key = (tuple(images.shape), W, max_length, start_id, end_id, ops.gemm_precision(),
+                   tuple((q.data_ptr(), q._version) for q in self.parameters()))
             cache = self.__dict__.setdefault("_ick_beam_graphs", {})
             ent = cache.get(key)
             if ent is None:

@@ -98,12 +98,18 @@ class KDTrainer:
     def __init__(self, student, teacher, projectors: Dict[str, nn.Module], *, vocab_size: int, alpha=0.7, beta=0.2,
                  gamma=0.1, temperature=4.0, learning_rate=2e-4, weight_decay=0.01, max_norm=1.0, batches_per_epoch=1000,
                  batch_size: int = 64, t_plus_1: int = 16, use_graph: bool = True, process_group=None,
-                 precision: str = "f32", teacher_precision: str = "f32", overlap_teacher: bool = True,
+                 precision: str = "f32", teacher_precision: Optional[str] = None, overlap_teacher: bool = True,
                  accumulation_steps: int = 1, loss_scale=None, growth_interval: int = 2000, bucketed: Optional[bool] = None):
         """precision: arithmetic of the student + projector contractions, forward and backward ("f32" exact; "fp16" = the
         reference's autocast regime :271-285 — fp16 MFMA products, fp32 accumulation and master weights, GradScaler on
         the device; "bf16" the same with bf16 products and no scaler; "bf16x3" split-bf16); the teacher runs
-        outside autocast in fp32 in the reference (:265-268) -> teacher_precision defaults to "f32"."""
+        outside autocast in fp32 in the reference (:265-268) -> teacher_precision is "f32" (exact fp32 MFMA)
+        under precision "f32" and "f32x3" otherwise: fp32-GRADE Linears from three fp16 MFMAs per product (igemm_glds_impl.h
+        TERMS 4; error against float64 equal to the exact kernel's, tests/test_gemm_gpu.py::test_f32x3_is_fp32_grade), 2x the
+        exact kernel — in the mixed-precision regimes the fp32 teacher is otherwise more than half of the step.
+        precision "f32x3": every forward Linear / convolution of the student that way too, every gradient launch exact fp32."""
+        if teacher_precision is None:
+            teacher_precision = "f32" if precision == "f32" else "f32x3"
         self.precision, self.teacher_precision = precision, teacher_precision
         if precision == "fp16" and loss_scale is None:
             loss_scale = 65536.0         # torch.amp.GradScaler's init_scale: fp16's 5-bit exponent needs it (reference :239)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ICK_ABI_VERSION 5
+#define ICK_ABI_VERSION 6
 
 const char* ick_last_error(void);
 int ick_abi_version(void);
@@ -84,7 +84,13 @@ int ick_gemm_f32(const IckGemm* desc, void* stream);
  * epilogues are those of ick_gemm_f32 (fp32 in HBM); values are rounded to bf16 on the way into LDS.
  * terms = 1: plain bf16 products; terms = 2: fp16 products (v_mfma_f32_32x32x16_f16 — the reference's autocast dtype: 10
  * mantissa bits, 5-bit exponent, to be run under the loss scaler); terms = 3: each operand split into hi + lo bf16 parts and
- * hi*hi + hi*lo + lo*hi accumulated (~1e-5 relative to the exact fp32 product, 3 MFMAs per k-step).
+ * hi*hi + hi*lo + lo*hi accumulated (~1e-5 relative to the exact fp32 product, 3 MFMAs per k-step); terms = 4 ("f32x3",
+ * round 3): fp32-GRADE products from three fp16 MFMAs — a = hi + 2^-11 lo', hi = fp16(a), lo' = fp16(2^11 (a - hi)); hi*hi in
+ * one accumulator, hi*lo' + lo'*hi in a second one folded in with 2^-11 after the k-loop — error against float64 equal to
+ * ick_gemm_f32's (tests/test_gemm_gpu.py::test_f32x3_is_fp32_grade) at half its time; NT and CONV_FWD descriptors the LDS-DMA
+ * kernel takes run it, every other descriptor is forwarded to ick_gemm_f32.  Operand magnitudes must lie in fp16's range
+ * (< 65504; values under 6e-5 keep an ABSOLUTE accuracy of 1.5e-11): meant for forward activations and weights — the host
+ * layer (ops.gemm_raw x3=True) never routes gradients here.
  * IckGemm.io16 (terms 1 / 2, shapes the LDS-DMA kernel takes): C / the residual stored as bf16 / fp16 — the 4-channel stem
  * convolution of the 16-bit training regime reads fp32 images and writes 16-bit activations this way.
  * Convolutions whose channel count is not a multiple of 32 run on the exact-fp32 kernel. */
@@ -108,6 +114,13 @@ int ick_cast_16_to_f32(const void* x, float* y, int64_t n, int fp16, void* strea
 int ick_attention_fwd_d64(const float* q, int64_t qld, int64_t qbs, const float* k, int64_t kld, int64_t kbs,
                           const float* v, int64_t vld, int64_t vbs, float* o, int64_t old, int64_t obs,
                           int B, int H, int Lq, int Lk, int causal, float scale, void* stream);
+/* The same contract with every product as three fp16 MFMAs (x = hi + 2^-11 lo'; fp32-grade: error against float64 equal to
+ * the fp32-MFMA kernel's, tests/test_attention_gpu.py) — v_mfma_f32_32x32x16_f16 instead of v_mfma_f32_32x32x2_f32, K and V
+ * split once per chunk on their way into LDS.  Operands inside fp16's range (the teacher's LayerNorm'd activations through a
+ * Linear); selected by the host layer under ops.precision("f32x3"). */
+int ick_attention_fwd_d64_x3(const float* q, int64_t qld, int64_t qbs, const float* k, int64_t kld, int64_t kbs,
+                             const float* v, int64_t vld, int64_t vbs, float* o, int64_t old, int64_t obs,
+                             int B, int H, int Lq, int Lk, int causal, float scale, void* stream);
 
 /* ------------------------------------------------------------------ layout transforms
  * images arrive as the reference hands them over: (B,3,224,224) fp32 NCHW (train_student_kd.py:259). */

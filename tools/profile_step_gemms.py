@@ -109,7 +109,7 @@ for r, n in cnt.items():
     ts = []
     kc = op in (0, 3)                                        # NT / CONV_FWD: the LDS-DMA kernel exists for 16-bit operands
     for tile in TILES:
-        if tile == 129 and (PREC != "f32" or op not in (0, 3)):
+        if tile == 129 and (PREC not in ("f32", "f32x3") or op not in (0, 3)):
             ts.append(float("inf"))          # loader-wave variant: exact-fp32 NT / CONV_FWD only
             continue
         if PREC == "f32x3" and tile > 255:
