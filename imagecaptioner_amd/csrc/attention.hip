@@ -34,8 +34,10 @@ struct AP {
   float scale;
 };
 
+// (seven-wave workgroups — the ViT's 197 tokens — are held to 128 VGPRs = four waves per SIMD: TWO workgroups per CU, so that
+//  the 384 (batch, head) workgroups of a B = 64 launch are resident at once instead of running as 256 + 128)
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AP p) {
+__global__ __launch_bounds__(NW * 64, NW == 7 ? 4 : 1) void attn_fwd_kernel(const AP p) {
   __shared__ __attribute__((aligned(16))) float Ks[2][KC][KP];
   __shared__ __attribute__((aligned(16))) float Vs[2][KC][D];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -164,7 +166,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AP p) {
 //     registers), so the online softmax is unchanged;
 //   * O^T += V^T P^T: the B fragment of k-step s is the lane's registers 8s..8s+7, i.e. keys {16s + 4 half + 0..3,
 //     16s + 8 + 4 half + 0..3} — the A fragment reads V^T at exactly those keys (two ds_read_b64), so P never moves
-//     between lanes here either; it is split in registers (probabilities lie in [0, 1]: the range fp16 is best at).
+//     between lanes here either; it is split in registers (probabilities lie in [0, 1]: pre-scaled by 2^11 they sit in the
+//     range fp16 is best at, and this product needs a single accumulator — see the comment at `ot`).
 // Operands must lie in fp16's range (LayerNorm'd activations through a Linear: they do); the host layer calls this entry only
 // under ops.precision("f32x3").
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -206,11 +209,15 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(const AP p) {
     ql[s] = __builtin_convertvector((x - __builtin_convertvector(qh[s], f32x8v)) * 2048.f, f16x8);
   }
 
-  f32x16 ot[2], ox[2];                             // O^T tiles (main / cross-term accumulators)
+  // O^T tiles, ONE accumulator at scale 2^11: the probabilities are <= 1, so P' = 2^11 p = Ph + Pl splits with an UNSCALED low
+  // part that stays a normal fp16 number down to p = 6e-5, and with ph = fp16(p) = 2^-11 Ph all three products
+  // V_h Ph + V_h Pl + V_l' ph carry the same factor 2^11 (V_l' = 2^11 (v - V_h) as everywhere): 32 registers fewer than a
+  // second accumulator (154 VGPRs; forcing 128 for two seven-wave workgroups per CU spills 18 and gains nothing: measured).
+  f32x16 ot[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { ot[t][r] = 0.f; ox[t][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) ot[t][r] = 0.f;
   float mrun = -INFINITY, lrun = 0.f;
 
   constexpr int NTH = NW * 64;
@@ -285,15 +292,17 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(const AP p) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { ot[t][r] *= alpha; ox[t][r] *= alpha; }
+      for (int r = 0; r < 16; ++r) ot[t][r] *= alpha;
     // ---- O^T (d x queries) += V^T (d x keys) . P^T (keys x queries): 2 k-steps x 2 tiles x 3 MFMAs
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
       f32x8v pv;
 #pragma unroll
       for (int j = 0; j < 8; ++j) pv[j] = st[8 * s + j];
-      const f16x8 ph = __builtin_convertvector(pv, f16x8);
-      const f16x8 pl = __builtin_convertvector((pv - __builtin_convertvector(ph, f32x8v)) * 2048.f, f16x8);
+      const f16x8 ph = __builtin_convertvector(pv, f16x8);                  // fp16(p) = 2^-11 Ph
+      const f32x8v pw = pv * 2048.f;
+      const f16x8 Ph = __builtin_convertvector(pw, f16x8);
+      const f16x8 Pl = __builtin_convertvector(pw - __builtin_convertvector(Ph, f32x8v), f16x8);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const _Float16* vh = &Vh[buf][32 * t + col][16 * s + 4 * half];
@@ -302,16 +311,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(const AP p) {
         const f16x4 vl0 = *reinterpret_cast<const f16x4*>(vl), vl1 = *reinterpret_cast<const f16x4*>(vl + 8);
         const f16x8 vhf = __builtin_shufflevector(vh0, vh1, 0, 1, 2, 3, 4, 5, 6, 7);
         const f16x8 vlf = __builtin_shufflevector(vl0, vl1, 0, 1, 2, 3, 4, 5, 6, 7);
-        ox[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlf, ph, ox[t], 0, 0, 0);
-        ox[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhf, pl, ox[t], 0, 0, 0);
-        ot[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhf, ph, ot[t], 0, 0, 0);
+        ot[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vlf, ph, ot[t], 0, 0, 0);
+        ot[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhf, Pl, ot[t], 0, 0, 0);
+        ot[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vhf, Ph, ot[t], 0, 0, 0);
       }
     }
     if (c + 1 < nchunks) stash(buf ^ 1);
     __syncthreads();
   }
   if (qok) {
-    const float inv = lrun > 0.f ? 1.f / lrun : 0.f;
+    const float inv = lrun > 0.f ? (1.f / 2048.f) / lrun : 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -319,7 +328,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(const AP p) {
         const int d0 = 32 * t + 8 * g + 4 * half;
         float o4[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o4[j] = (ot[t][4 * g + j] + ox[t][4 * g + j] * (1.f / 2048.f)) * inv;
+        for (int j = 0; j < 4; ++j) o4[j] = ot[t][4 * g + j] * inv;
         *reinterpret_cast<float4*>(O + (long)qrow * p.old + d0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
       }
   }

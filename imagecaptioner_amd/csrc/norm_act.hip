@@ -1008,13 +1008,13 @@ int ick_maxpool3x3s2_bwd(const float* x, const float* dy, float* dx, int B, int 
 }
 
 int ick_adaptive_avgpool_fwd(const float* x, float* y, int B, int H, int W, int C, int Ho, int Wo, void* stream) {
-  ICK_REQUIRE(x && y && C % 4 == 0 && Ho > 0 && Wo > 0 && H >= Ho && W >= Wo, "ick_adaptive_avgpool_fwd: bad arguments");
+  ICK_REQUIRE(x && y && C % 4 == 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0, "ick_adaptive_avgpool_fwd: bad arguments");   // (H < Ho: bins replicate, as torch's)
   ICK_LAUNCH(adaptive_avgpool_fwd_kernel, dim3(grid_for((long)B * Ho * Wo * (C / 4))), dim3(NT), 0, ST, x, y, B, H, W, C / 4, Ho, Wo);
   return ick::launch_status("adaptive_avgpool_fwd");
 }
 
 int ick_adaptive_avgpool_bwd(const float* dy, float* dx, int B, int H, int W, int C, int Ho, int Wo, void* stream) {
-  ICK_REQUIRE(dy && dx && C % 4 == 0 && Ho > 0 && Wo > 0 && H >= Ho && W >= Wo, "ick_adaptive_avgpool_bwd: bad arguments");
+  ICK_REQUIRE(dy && dx && C % 4 == 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0, "ick_adaptive_avgpool_bwd: bad arguments");
   ICK_LAUNCH(adaptive_avgpool_bwd_kernel, dim3(grid_for((long)B * H * W * (C / 4))), dim3(NT), 0, ST, dy, dx, B, H, W, C / 4, Ho, Wo);
   return ick::launch_status("adaptive_avgpool_bwd");
 }

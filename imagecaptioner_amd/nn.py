@@ -341,10 +341,11 @@ def _wlike(conv: Conv2d, like: torch.Tensor) -> torch.Tensor:
 
 
 def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool, w_packed=None, arena=None, counters=None,
-            out_dtype=None):
+            out_dtype=None, keep_raw: bool = True):
     """raw = conv(x); y = [relu](bn(raw) [+ residual]).  Train mode: batch statistics from the conv epilogue (fp64
     sums), normalisation + running-stat update in one pass over raw (also for frozen layers).
-    Returns (y, raw, mean, invstd).  16-bit x: 16-bit weights, raw and y (out_dtype: the stem's fp32 images -> 16-bit)."""
+    Returns (y, raw, mean, invstd).  16-bit x: 16-bit weights, raw and y (out_dtype: the stem's fp32 images -> 16-bit).
+    keep_raw=False (layers nobody differentiates through: the frozen stem / layer1 / layer2): y overwrites raw."""
     w = w_packed if w_packed is not None else _wlike(conv, x)
     if train:
         bn._ick_eval_co = None       # running statistics (and soon the affine parameters) change under raw kernels
@@ -355,7 +356,7 @@ def conv_bn(x, conv: Conv2d, bn: BatchNorm2d, relu: bool, residual, train: bool,
                  torch.zeros(2 * R, C, dtype=torch.float64, device=x.device)).view(2, R, C)
         raw = ops.conv_fwd(x, w, conv.stride, conv.padding, stats=(stats[0], stats[1]), out_dtype=out_dtype)
         y, mean, inv = ops.bn_train_apply(raw, stats, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum,
-                                          bn.eps, residual, relu)
+                                          bn.eps, residual, relu, inplace=not keep_raw)
         if counters is not None:
             counters.append(bn.num_batches_tracked)
         else:
@@ -410,10 +411,10 @@ def _block_trainable(blk: Bottleneck) -> bool:
     return any(p.requires_grad for p in blk.parameters())
 
 
-def bottleneck_forward(blk: Bottleneck, x, train: bool, arena=None, counters=None):
+def bottleneck_forward(blk: Bottleneck, x, train: bool, arena=None, counters=None, keep_raw: bool = True):
     """One torchvision Bottleneck on NHWC activations: out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + identity).
     Returns (out, rec); rec holds what bottleneck_backward needs (raw conv outputs, activations, saved statistics)."""
-    cb = lambda t, c, b, relu, res: conv_bn(t, c, b, relu, res, train, arena=arena, counters=counters)
+    cb = lambda t, c, b, relu, res: conv_bn(t, c, b, relu, res, train, arena=arena, counters=counters, keep_raw=keep_raw)
     a1, r1, m1, i1 = cb(x, blk.conv1, blk.bn1, True, None)
     a2, r2, m2, i2 = cb(a1, blk.conv2, blk.bn2, True, None)
     if blk.downsample is not None:
@@ -516,16 +517,16 @@ class ResNetTrunkFn(Function):
         # 16-bit in, 16-bit out)
         dt16 = _H16_OF.get(ops.gemm_precision()) if (_TRUNK16[0] and (not train or not stem_trainable)) else None
         ctx.dt16 = dt16
-        ys, raw_s, mean_s, inv_s = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters,
-                                           out_dtype=dt16)
-        y = ops.maxpool3x3s2(ys)
         first = 0 if stem_trainable else next((i for i, b in enumerate(blocks) if _block_trainable(b)), len(blocks))
         want_bwd = any(ctx.needs_input_grad) and first < len(blocks)   # (forward itself always runs in no-grad mode)
         ctx.eval_mode_graph = want_bwd and not train     # eval forward under autograd (validation loops): fine until .backward()
         want_bwd = want_bwd and train
+        ys, raw_s, mean_s, inv_s = conv_bn(x4, stem, resnet[1], True, None, train, w_packed=w4, arena=arena, counters=counters,
+                                           out_dtype=dt16, keep_raw=want_bwd and stem_trainable)
+        y = ops.maxpool3x3s2(ys)
         recs = []
         for i, blk in enumerate(blocks):
-            y, rec = bottleneck_forward(blk, y, train, arena, counters)
+            y, rec = bottleneck_forward(blk, y, train, arena, counters, keep_raw=want_bwd and i >= first)
             if want_bwd and i >= first:
                 recs.append(rec)
         if counters:

@@ -598,11 +598,13 @@ def bn_bwd(dy, y_mask, x, mean, invstd, gamma, dgamma, dbeta, want_g: bool, batc
     return dx, g
 
 
-def bn_train_apply(raw, stats, gamma, beta, rmean, rvar, momentum, eps, residual, relu: bool):
+def bn_train_apply(raw, stats, gamma, beta, rmean, rvar, momentum, eps, residual, relu: bool, inplace: bool = False):
     """y = [relu](batchnorm_train(raw) [+ residual]) from the fp64 sums of the conv epilogue, one pass; returns
-    (y, save_mean, save_invstd) and updates the running statistics."""
+    (y, save_mean, save_invstd) and updates the running statistics.  inplace: y overwrites raw (layers without a backward:
+    the raw convolution output is needed by the BatchNorm adjoint only; the pass is elementwise, every thread reads the
+    element it writes) — no second activation-sized allocation, and the stores land on lines the read just brought in."""
     C = raw.shape[-1]
-    y = torch.empty_like(raw)
+    y = raw if inplace else torch.empty_like(raw)
     sv = empty(2, C, device=raw.device)
     copies = stats[0].shape[0] if stats[0].dim() == 2 else 1
     if raw.dtype in _H16:      # 16-bit activation storage

@@ -53,8 +53,8 @@ class CNNEncoder(nn.Module):
         self.embed_size = embed_size
 
     def forward(self, images):
-        if images.shape[-2] < 193 or images.shape[-1] < 193:
-            raise ValueError("inputs smaller than 193x193 leave the trunk with fewer than 7x7 positions to pool into (7,7)")
+        # (any size the five stride-2 stages leave non-empty: nn.AdaptiveAvgPool2d((7,7)) replicates bins when the feature map
+        #  is smaller than 7x7, reference student_model.py:34,60, and so do ick_adaptive_avgpool_fwd / _bwd)
         f = hnn.resnet_trunk(images, self.resnet, self.training)     # (B,49,2048), NHWC rows (adaptive-pooled if not 224x224)
         return self.projection(f)                                    # (B,49,E)
 

@@ -374,6 +374,8 @@ def test_staged_data_parallel_step_under_an_rccl_group_equals_single_graph_step(
                 tr.train_step()         #  order of fp32 atomics, and at B = 2 fp16 activation rounding amplifies that to ~18 % in the
             torch.cuda.synchronize()    #  trunk's gradients: a property of the problem at this batch, not of the staging)
             deltas[staged] = (tr.flat.param.clone() - before, tr.loss_dict()["total_loss"], tr.flat.grad.clone())
+            names = {id(q): k for k, q in s.named_parameters()}
+            metas = [(names.get(id(q), "projector"), o, n) for q, o, n in tr.flat.metas]
             del tr, s, t, p
             torch.cuda.empty_cache()
         finally:
@@ -385,6 +387,22 @@ def test_staged_data_parallel_step_under_an_rccl_group_equals_single_graph_step(
     # same kernels in the same order: the two steps differ only by the order of fp32 atomics
     assert float((g0 - g1).norm()) <= 2e-2 * float(g0.norm())
     assert float((d0 - d1).abs().mean()) <= 2e-3 * float(d0.abs().mean())
+    # per tensor (a norm over the whole buffer lets one dropped BatchNorm gradient or one of the 15 timesteps pass):
+    # trunk tensors carry the train-mode-BatchNorm amplification of the atomics' order at this batch, everything behind the
+    # trunk's output does not
+    worst = {"trunk": (0.0, ""), "rest": (0.0, "")}
+    for name, o, n in metas:
+        a, b = g0[o:o + n].double(), g1[o:o + n].double()
+        if float(a.norm()) == 0.0:
+            assert float(b.norm()) == 0.0, name
+            continue
+        e = float((a - b).norm() / a.norm())
+        grp = "trunk" if name.startswith("encoder.resnet.") else "rest"
+        if e > worst[grp][0]:
+            worst[grp] = (e, name)
+    print("staged vs single graph, worst per-tensor gradient difference:", worst)
+    if precision == "f32":
+        assert worst["trunk"][0] < 5e-2 and worst["rest"][0] < 5e-4, worst      # measured 1.8e-3 .. 7.4e-3 and 2.5e-5
 
 
 def test_staged_step_on_16bit_storage_equals_single_graph_step():
