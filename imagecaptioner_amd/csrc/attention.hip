@@ -53,8 +53,9 @@ __global__ __launch_bounds__(NW * 64, NW == 7 ? 4 : 1) void attn_fwd_kernel(cons
 
   // B operand of S^T = K Q^T: lane (query col, half) needs Q[query][d = 2kk + half], kk = 0..31, pre-scaled
   float qf[32];
+  const float qscale = p.scale * 1.44269504088896340736f;   // scores in the log2 domain: the softmax is exp2 (one v_exp_f32 each)
 #pragma unroll
-  for (int kk = 0; kk < 32; ++kk) qf[kk] = qok ? Q[(long)qrow * p.qld + 2 * kk + half] * p.scale : 0.f;
+  for (int kk = 0; kk < 32; ++kk) qf[kk] = qok ? Q[(long)qrow * p.qld + 2 * kk + half] * qscale : 0.f;
 
   f32x16 ot[2];                                    // O^T tiles: rows d = 32t + (r&3)+8(r>>2)+4half, column = query
 #pragma unroll
@@ -117,10 +118,10 @@ __global__ __launch_bounds__(NW * 64, NW == 7 ? 4 : 1) void attn_fwd_kernel(cons
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
     const float mnew = fmaxf(mrun, cmax);
     const float msafe = mnew == -INFINITY ? 0.f : mnew;           // fully masked so far: keep everything at 0
-    const float alpha = expf(mrun - msafe);                       // exp(-inf) = 0 on the first chunk
+    const float alpha = __builtin_amdgcn_exp2f(mrun - msafe);                       // exp(-inf) = 0 on the first chunk
     float csum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - msafe); csum += st[r]; }
+    for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - msafe); csum += st[r]; }
     csum += __shfl_xor(csum, 32);
     lrun = lrun * alpha + csum;
     mrun = mnew;
@@ -199,12 +200,13 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(const AP p) {
   const bool qok = qrow < p.Lq;
 
   // B operand of S^T = K Q^T, k-step s (16 d): lane (query col, half) supplies d = 16 s + 8 half + 0..7, pre-scaled
+  const float qscale = p.scale * 1.44269504088896340736f;   // log2 domain, as in attn_fwd_kernel
   f16x8 qh[4], ql[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     f32x8v x;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = qok ? Q[(long)qrow * p.qld + 16 * s + 8 * half + j] * p.scale : 0.f;
+    for (int j = 0; j < 8; ++j) x[j] = qok ? Q[(long)qrow * p.qld + 16 * s + 8 * half + j] * qscale : 0.f;
     qh[s] = __builtin_convertvector(x, f16x8);
     ql[s] = __builtin_convertvector((x - __builtin_convertvector(qh[s], f32x8v)) * 2048.f, f16x8);
   }
@@ -282,10 +284,10 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_x3_kernel(const AP p) {
     cmax = fmaxf(cmax, __shfl_xor(cmax, 32));
     const float mnew = fmaxf(mrun, cmax);
     const float msafe = mnew == -INFINITY ? 0.f : mnew;
-    const float alpha = expf(mrun - msafe);
+    const float alpha = __builtin_amdgcn_exp2f(mrun - msafe);
     float csum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { st[r] = expf(st[r] - msafe); csum += st[r]; }
+    for (int r = 0; r < 16; ++r) { st[r] = __builtin_amdgcn_exp2f(st[r] - msafe); csum += st[r]; }
     csum += __shfl_xor(csum, 32);
     lrun = lrun * alpha + csum;
     mrun = mnew;
