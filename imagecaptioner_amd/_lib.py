@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libick.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "ick.h")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 OP_NT, OP_NN, OP_TN, OP_CONV_FWD, OP_CONV_FWD_C4, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_CONV_DGRAD_S2 = range(8)
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = range(4)
 ACT_POST_RESIDUAL = 16

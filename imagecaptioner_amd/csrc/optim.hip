@@ -52,7 +52,10 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ g, float
                              long n, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
                              const float* __restrict__ norm, float max_norm, float inv_scale, int write_clipped,
                              const float* __restrict__ hyper, const float* __restrict__ scaler) {
-  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2]; }  // device-resident schedule (hipGraph replay)
+  if (hyper) {  // device-resident schedule (hipGraph replay); hyper[3] > 0: this step's beta1 (OneCycleLR's momentum cycling)
+    lr = hyper[0]; bc1 = hyper[1]; bc2 = hyper[2];
+    if (hyper[3] > 0.f) b1 = hyper[3];
+  }
   if (scaler) {   // dynamic loss scaling (torch.amp.GradScaler semantics): scaler = {scale, 1/scale, found_inf}
     if (scaler[2] != 0.f) return;                                 // scaler.step(): skip the update on inf / nan gradients
     inv_scale *= scaler[1];                                       // scaler.unscale_()
@@ -91,13 +94,17 @@ __global__ void loss_scale_update_kernel(float* __restrict__ st, float growth, f
 
 __global__ void adam_bias_correction_kernel(long* __restrict__ steps, const float* __restrict__ scaler, double b1, double b2,
                                             float* __restrict__ hyper, int n_groups, int stride,
-                                            const float* __restrict__ lr_in) {
+                                            const float* __restrict__ lr_in, const float* __restrict__ beta1_in) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   long t = steps[0];
   if (!scaler || scaler[2] == 0.f) steps[0] = ++t; else ++t;   // skipped step: the values are unused (adamw returns early)
-  const float bc1 = (float)(1.0 - pow(b1, (double)t)), bc2 = (float)(1.0 - pow(b2, (double)t));
+  const float bc2 = (float)(1.0 - pow(b2, (double)t));
   for (int g = 0; g < n_groups; ++g) {
-    hyper[g * stride + 1] = bc1; hyper[g * stride + 2] = bc2;
+    // beta1_in: this step's beta1 per group (torch's OneCycleLR cycles it against the learning rate); torch.optim.AdamW then
+    // forms 1 - beta1^t from the CURRENT beta1 — so does this
+    const double b1g = beta1_in ? (double)beta1_in[g] : b1;
+    hyper[g * stride + 1] = (float)(1.0 - pow(b1g, (double)t)); hyper[g * stride + 2] = bc2;
+    if (beta1_in) hyper[g * stride + 3] = beta1_in[g];
     if (lr_in) hyper[g * stride] = lr_in[g];   // this step's learning rates, uploaded as ONE contiguous block by the host
   }
 }
@@ -130,11 +137,12 @@ int ick_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, 
 }
 
 int ick_adam_bias_correction(int64_t* applied_steps, const float* scaler, double beta1, double beta2, float* hyper,
-                             int n_groups, int stride, const float* lr_in, void* stream) {
+                             int n_groups, int stride, const float* lr_in, const float* beta1_in, void* stream) {
   ICK_REQUIRE(applied_steps && hyper && n_groups > 0 && stride >= 3 && beta1 > 0. && beta1 < 1. && beta2 > 0. && beta2 < 1.,
               "ick_adam_bias_correction: bad arguments");
+  ICK_REQUIRE(!beta1_in || stride >= 4, "ick_adam_bias_correction: beta1_in needs hyper rows of at least 4 floats");
   ICK_LAUNCH(adam_bias_correction_kernel, dim3(1), dim3(64), 0, ST, (long*)applied_steps, scaler, beta1, beta2,
-             hyper, n_groups, stride, lr_in);
+             hyper, n_groups, stride, lr_in, beta1_in);
   return ick::launch_status("adam_bias_correction");
 }
 

@@ -938,13 +938,16 @@ def adamw_step(p, g, m, v, lr, betas, eps, wd, step, norm=None, max_norm=1.0, in
 
 
 def adam_bias_correction(applied_steps: torch.Tensor, scaler: Optional[torch.Tensor], betas, hyper: torch.Tensor,
-                         lr_in: Optional[torch.Tensor] = None) -> None:
+                         lr_in: Optional[torch.Tensor] = None, beta1_in: Optional[torch.Tensor] = None) -> None:
     """t = ++applied_steps unless the GradScaler found inf/nan; hyper[g][1..2] = 1-beta1^t, 1-beta2^t for every row g;
-    hyper[g][0] = lr_in[g] when lr_in (contiguous, one float per row) is given."""
+    hyper[g][0] = lr_in[g] when lr_in (contiguous, one float per row) is given; beta1_in (one float per row): this step's
+    beta1 (OneCycleLR's momentum cycling) -> hyper[g][3], read by adamw_step."""
     assert applied_steps.dtype == torch.int64 and hyper.is_contiguous()
     assert lr_in is None or (lr_in.is_contiguous() and lr_in.numel() >= hyper.shape[0])
+    assert beta1_in is None or (beta1_in.is_contiguous() and beta1_in.numel() >= hyper.shape[0] and hyper.shape[1] >= 4)
     check(_lib.lib().ick_adam_bias_correction(applied_steps.data_ptr(), _ptr(scaler), betas[0], betas[1], hyper.data_ptr(),
-                                              hyper.shape[0], hyper.shape[1], _ptr(lr_in), _st()), "ick_adam_bias_correction")
+                                              hyper.shape[0], hyper.shape[1], _ptr(lr_in), _ptr(beta1_in), _st()),
+          "ick_adam_bias_correction")
 
 
 def loss_scale_check(norms: torch.Tensor, state: torch.Tensor) -> None:

@@ -126,3 +126,121 @@ class OptimizedDistillationLoss(nn.Module):
         out7 = self.forward_device(student_outputs, teacher_outputs, targets, attention_weights)
         vals = out7.detach().cpu().tolist()                 # one host sync (the reference does seven .item() calls)
         return out7[0], dict(zip(KEYS, vals))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The "optimized" training recipe (/root/reference/src/train_student_kd_optimized.py:338-378, :400-452) on the flat-buffer /
+# hipGraph trainer: CompactCaptioningStudent (or any student with .encoder / .decoder), OptimizedDistillationLoss, AdamW with
+# the reference's three parameter groups, torch's OneCycleLR INCLUDING its default momentum cycling.
+def one_cycle(step: int, total_steps: int, max_lr: float, pct_start: float = 0.1, div_factor: float = 10.0,
+              final_div_factor: float = 100.0, base_momentum: float = 0.85, max_momentum: float = 0.95) -> Tuple[float, float]:
+    """(lr, beta1) torch.optim.lr_scheduler.OneCycleLR(anneal_strategy='cos', three_phase=False, cycle_momentum=True) holds
+    after `step` scheduler steps — the values optimizer step number `step` (0-based) runs with in the reference loop, which
+    steps the scheduler after every optimizer step (:449-452)."""
+    import math
+    initial, min_lr = max_lr / div_factor, max_lr / div_factor / final_div_factor
+    phases = ((float(pct_start * total_steps) - 1.0, initial, max_lr, max_momentum, base_momentum),
+              (float(total_steps - 1), max_lr, min_lr, base_momentum, max_momentum))
+    cos = lambda a, b, pct: b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+    start = 0.0
+    for i, (end, lr0, lr1, m0, m1) in enumerate(phases):
+        if step <= end or i == len(phases) - 1:
+            pct = (step - start) / (end - start)
+            return cos(lr0, lr1, pct), cos(m0, m1, pct)
+        start = end
+    raise AssertionError
+
+
+def _make_optimized_trainer():
+    from .train_student_kd import KDTrainer
+
+    class OptimizedKDTrainer(KDTrainer):
+        """KDTrainer with the reference's optimized recipe.  Differences from the base class, all from the reference file:
+        loss = OptimizedDistillationLoss (its `epoch` attribute is driven through set_epoch(): the weights are constants of
+        the captured graph, a change re-captures); parameter groups encoder lr x0.1 / wd 0.01, decoder x1 / 0.01, refinement +
+        projectors x1.5 / 0.005 (:361-366); OneCycleLR over `total_steps` optimizer steps with pct_start 0.1, cos, div 10,
+        final div 100 (:369-378) and torch's default momentum cycling: Adam's beta1 runs 0.95 -> 0.85 -> 0.95 against the
+        learning rate, read by the AdamW kernel from device memory like the learning rate (ick_adam_bias_correction beta1_in)."""
+        GROUP_LR = {"encoder": 0.1, "decoder": 1.0, "refine": 1.5, "projector": 1.5}
+        GROUP_WD = {"encoder": 0.01, "decoder": 0.01, "refine": 0.005, "projector": 0.005}
+
+        def __init__(self, student, teacher, projectors, *, vocab_size: int, total_steps: int, learning_rate: float = 5e-4,
+                     alpha=0.7, beta=0.2, gamma=0.1, temperature=4.0, precision: str = "f32", **kw):
+            if precision not in ("f32", "f32x3"):
+                raise NotImplementedError("OptimizedKDTrainer: the MobileNetV2 trunk has no 16-bit storage path; precision f32 / f32x3")
+            if kw.get("accumulation_steps", 1) != 1:
+                raise NotImplementedError("OptimizedKDTrainer: accumulation_steps > 1")
+            super().__init__(student, teacher, projectors, vocab_size=vocab_size, alpha=alpha, beta=beta, gamma=gamma,
+                             temperature=temperature, learning_rate=learning_rate, precision=precision, **kw)
+            self.loss = OptimizedDistillationLoss(alpha, beta, gamma, temperature, vocab_size)
+            self.total_steps = int(total_steps)
+            cuda = self.device.type == "cuda"
+            # [lr x 4 groups | beta1 x 4 groups]: ONE contiguous upload per optimizer step
+            self._hyper_ring = [torch.zeros(8, dtype=torch.float32).pin_memory() if cuda else torch.zeros(8) for _ in range(8)]
+            self.lr_dev = torch.zeros(8, dtype=torch.float32, device=self.device)
+            self._weights_captured = None
+
+        # ---- schedule
+        def set_epoch(self, epoch: int) -> None:
+            """distill_loss.epoch = epoch (:399).  The warm-up weights are kernel arguments inside the captured graph: when they
+            change (epochs 0..warmup_epochs) the graphs are dropped and re-captured at the next step."""
+            self.loss.epoch = int(epoch)
+            if self.g_fb is not None and self._weights_captured != self.loss.current_weights():
+                self.g_fb = self.g_opt = None
+
+        def _capture(self):
+            self._weights_captured = self.loss.current_weights()
+            super()._capture()
+
+        def _update_hyper(self):
+            slot = self._hyper_slot
+            self._hyper_slot = (slot + 1) % len(self._hyper_ring)
+            if self._hyper_events[slot] is not None:
+                self._hyper_events[slot].synchronize()
+            host = self._hyper_ring[slot]
+            k = min(self.step_count, self.total_steps - 1)        # (torch raises beyond total_steps; the last values are kept here)
+            for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
+                host[gi], host[4 + gi] = one_cycle(k, self.total_steps, self.lr * self.GROUP_LR[name])
+            self.lr_dev.copy_(host, non_blocking=True)
+            if self.device.type == "cuda":
+                ev = torch.cuda.Event()
+                ev.record()
+                self._hyper_events[slot] = ev
+
+        # ---- optimizer: clip student / clip per projector / AdamW per group (:441-452)
+        def _optimizer(self):
+            f = self.flat
+            inv = 1.0 / self.world
+            a0, _ = f.segment("encoder")
+            _, b2 = f.segment("refine")
+            pa, pb = f.segment("projector")
+            ops.grad_norm(f.grad[a0:b2], self.ws, self.norms[0:1])
+            if pb > pa:
+                ops.grad_norm(f.grad[pa:pb], self.ws, self.norms[1:2])
+            if self.scaler is not None:
+                ops.loss_scale_check(self.norms, self.scaler)
+            ops.adam_bias_correction(self.applied_steps_dev, self.scaler, self.betas, self.hyper, self.lr_dev[:4], beta1_in=self.lr_dev[4:])
+            dry = self.wd == 0.0                                   # (_optimizer_dry: warm-up launches that must change nothing)
+            for gi, name in enumerate(("encoder", "decoder", "refine", "projector")):
+                a, b = f.segment(name)
+                if b <= a:
+                    continue
+                norm = self.norms[1:2] if name == "projector" else self.norms[0:1]
+                ops.adamw_step(f.param[a:b], f.grad[a:b], f.exp_avg[a:b], f.exp_avg_sq[a:b], 0.0, self.betas, self.eps,
+                               0.0 if dry else self.GROUP_WD[name], 0, norm=norm, max_norm=self.max_norm, inv_scale=inv,
+                               hyper=self.hyper[gi], scaler=self.scaler)
+            if self.scaler is not None:
+                ops.loss_scale_update(self.scaler, 2.0, 0.5, self.growth_interval)
+
+        def loss_dict(self) -> Dict[str, float]:
+            return dict(zip(KEYS, self.out5.detach().cpu().tolist()))
+
+    return OptimizedKDTrainer
+
+
+def __getattr__(name):            # OptimizedKDTrainer is built on first use (train_student_kd imports this module's loss lazily too)
+    if name == "OptimizedKDTrainer":
+        cls = _make_optimized_trainer()
+        globals()["OptimizedKDTrainer"] = cls
+        return cls
+    raise AttributeError(name)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ICK_ABI_VERSION 6
+#define ICK_ABI_VERSION 7
 
 const char* ick_last_error(void);
 int ick_abi_version(void);
@@ -301,9 +301,12 @@ int ick_adamw_step(float* p, float* g, float* m, float* v, int64_t n, float lr, 
  * torch's scaler.step(optimizer) leaves state['step'] untouched on a skipped step — then hyper[g*stride + 1] = 1 - beta1^t,
  * hyper[g*stride + 2] = 1 - beta2^t for g < n_groups (the rows ick_adamw_step reads), so a replayed hipGraph needs no
  * host-computed bias correction.  lr_in (optional, n_groups contiguous floats): hyper[g*stride] = lr_in[g] — the host
- * uploads the schedule's learning rates as one contiguous pinned block and this kernel scatters them into the rows. */
+ * uploads the schedule's learning rates as one contiguous pinned block and this kernel scatters them into the rows.
+ * beta1_in (optional, n_groups floats; rows of >= 4 floats): this step's beta1 per group — torch's OneCycleLR cycles Adam's
+ * beta1 against the learning rate (train_student_kd_optimized.py:369-378) — stored in hyper[g*stride + 3], which
+ * ick_adamw_step uses instead of its beta1 argument when it is > 0, and used for 1 - beta1^t as torch.optim.AdamW does. */
 int ick_adam_bias_correction(int64_t* applied_steps, const float* scaler, double beta1, double beta2, float* hyper,
-                             int n_groups, int stride, const float* lr_in, void* stream);
+                             int n_groups, int stride, const float* lr_in, const float* beta1_in, void* stream);
 /* torch.amp.GradScaler (train_student_kd.py:239,288-298) as device state {scale, 1/scale, found_inf, good_steps}:
  * _check marks found_inf from the norms of the scaled gradients (unscale_), ick_adamw_step(scaler=state) unscales and
  * skips on found_inf (scaler.step), _update applies growth / backoff (scaler.update). */

@@ -36,3 +36,9 @@ COMPACT_B16_KEYS = {
     "decoder.lstm.weight_hh_l0": np.s_[::16, ::4], "decoder.lstm.weight_ih_l0": np.s_[::16, ::4],
     "decoder.embedding.weight": np.s_[::40, ::4], "decoder.output_projection.weight": np.s_[::40, ::4],
 }
+
+# the optimized recipe's five steps (tests/golden/optimized_recipe.npz): parameter CHANGES after the last step
+OPT_RECIPE_KEYS = {"encoder.projection.0.weight": np.s_[::4, ::16], "encoder.backbone.18.0.weight": np.s_[::8, ::4, 0, 0],
+                   "encoder.backbone.14.conv.2.weight": np.s_[::4, ::8, 0, 0], "decoder.attention.weight": np.s_[::4, ::4],
+                   "decoder.lstm.weight_hh_l0": np.s_[::16, ::4], "decoder.lstm.bias_ih_l0": np.s_[:], "decoder.embedding.weight": np.s_[::40, ::4],
+                   "decoder.output_projection.weight": np.s_[::40, ::4], "projector.feature_projection.0.weight": np.s_[::4, ::8]}

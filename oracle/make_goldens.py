@@ -566,6 +566,76 @@ def golden_optloss():
     npz("optloss.npz", **out)
 
 
+from oracle.make_golden_keys import OPT_RECIPE_KEYS  # noqa: E402
+
+
+def golden_optimized_recipe(B=8, steps=5, total_steps=20, lr=1e-3):
+    """N4: the reference's "optimized" training recipe (/root/reference/src/train_student_kd_optimized.py:338-378, :400-452) run
+    for `steps` optimizer steps on its own classes — CompactCaptioningStudent + OptimizedDistillationLoss, AdamW with the three
+    parameter groups (lr x0.1 / x1 / x1.5, weight decay 0.01 / 0.01 / 0.005), OneCycleLR (pct_start 0.1, cos, div 10, final div
+    100; torch's default cycle_momentum cycles Adam's beta1 0.95 <-> 0.85), clip_grad_norm_ 1.0 on the student and per projector.
+    fp32 on the CPU (no autocast / scaler: as in the other goldens), dropout p = 0, the loss's epoch attribute 0 for the first
+    two steps and 2 afterwards.  Recorded: the schedule (lr and beta1 per group per step), the loss terms per step, the gradient
+    norms, and slices of the parameter CHANGE after the last step."""
+    import types
+    import torchvision
+    tr = types.ModuleType("torchvision.transforms")
+    sys.modules["torchvision.transforms"] = tr
+    torchvision.transforms = tr
+    dl = types.ModuleType("data_loader")
+    dl.get_loader = None
+    sys.modules["data_loader"] = dl
+    import student_model_compact as ref_compact
+    import train_student_kd_optimized as ref_opt
+    from torch.optim.lr_scheduler import OneCycleLR
+    torch.manual_seed(0)
+    t = build_teacher()
+    s = ref_compact.CompactCaptioningStudent(V, 256, 256, 1, use_attention_refinement=False)
+    apply_seeded_init(s, seed=7)
+    zero_dropout(s)
+    s.train()
+    projectors = ref_kd.create_feature_projectors(t, s)
+    apply_seeded_init(projectors["encoder"], seed=2)
+    zero_dropout(projectors["encoder"])
+    L = ref_opt.OptimizedDistillationLoss(alpha=0.7, beta=0.2, gamma=0.1, temperature=4.0, vocab_size=V)
+    other = [q for pr in projectors.values() for q in pr.parameters()]
+    opt = torch.optim.AdamW([{"params": list(s.encoder.parameters()), "lr": lr * 0.1, "weight_decay": 0.01},
+                             {"params": list(s.decoder.parameters()), "lr": lr, "weight_decay": 0.01},
+                             {"params": other, "lr": lr * 1.5, "weight_decay": 0.005}], betas=(0.9, 0.999), eps=1e-8)
+    sched = OneCycleLR(opt, max_lr=[lr * 0.1, lr, lr * 1.5], total_steps=total_steps, pct_start=0.1, anneal_strategy="cos",
+                       div_factor=10, final_div_factor=100)
+    named = dict(s.named_parameters())
+    named.update({f"projector.{k}": q for k, q in projectors["encoder"].named_parameters()})
+    init = {k: named[k].detach().clone() for k in OPT_RECIPE_KEYS}
+    images, caps = synthetic_batch(B, V, T1, seed=4321)
+    cin, ctg = caps[:-1], caps[1:]
+    tw = ref_kd.TeacherWrapper(t)
+    out = dict(B=B, total_steps=total_steps, lr=lr)
+    lrs, b1s, vals, norms = [], [], [], []
+    for k in range(steps):
+        L.epoch = 0 if k < 2 else 2
+        lrs.append([g["lr"] for g in opt.param_groups])
+        b1s.append([g["betas"][0] for g in opt.param_groups])
+        with torch.no_grad():
+            t_out = tw(images.float(), cin.long())
+        logits, enc, hids, _ = s(images, cin)
+        t_out["encoder_features"] = projectors["encoder"](t_out["encoder_features"])
+        loss, d = L({"logits": logits, "encoder_features": enc, "hidden_states": hids}, t_out, ctg)
+        loss.backward()
+        n1 = torch.nn.utils.clip_grad_norm_(s.parameters(), max_norm=1.0)
+        n2 = torch.nn.utils.clip_grad_norm_(projectors["encoder"].parameters(), max_norm=1.0)
+        opt.step()
+        opt.zero_grad()
+        sched.step()
+        vals.append([d[q] for q in ("total_loss", "token_kd_loss", "feature_kd_loss", "hidden_kd_loss", "kd_loss", "hard_loss", "ce_loss")])
+        norms.append([float(n1), float(n2)])
+        print("step", k, L.epoch, vals[-1][0], norms[-1], lrs[-1][1], b1s[-1][1])
+    out.update(lrs=np.array(lrs, np.float64), beta1s=np.array(b1s, np.float64), values=np.array(vals, np.float64), norms=np.array(norms, np.float64))
+    for k, sl in OPT_RECIPE_KEYS.items():
+        out["delta:" + k] = (named[k].detach() - init[k])[sl]
+    npz("optimized_recipe.npz", **out)
+
+
 def golden_param_counts():
     """SURVEY.md §0 fact 10 — pins the architecture sizes."""
     torch.manual_seed(0)
@@ -587,6 +657,6 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["counts", "losses", "projector", "refinement", "decoders", "cfg1", "teacher", "kd_step", "kd_step_b16", "compact", "beam", "optloss"]
     fns = {"counts": golden_param_counts, "losses": golden_losses, "projector": golden_projector,
            "refinement": golden_refinement, "decoders": golden_decoders, "cfg1": golden_cfg1,
-           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "kd_step_b16_autocast": golden_kd_step_b16_autocast, "kd_step_cfg5_b16": golden_kd_step_cfg5_b16, "compact": golden_compact, "compact_layers": golden_compact_decoder_layers, "compact_b16": golden_compact_b16, "beam": golden_beam, "optloss": golden_optloss}
+           "teacher": golden_teacher, "kd_step": golden_kd_step, "kd_step_b16": golden_kd_step_b16, "kd_step_b16_autocast": golden_kd_step_b16_autocast, "kd_step_cfg5_b16": golden_kd_step_cfg5_b16, "compact": golden_compact, "compact_layers": golden_compact_decoder_layers, "compact_b16": golden_compact_b16, "beam": golden_beam, "optloss": golden_optloss, "optimized_recipe": golden_optimized_recipe}
     for w in which:
         fns[w]()

@@ -20,7 +20,7 @@ def test_header_symbols_are_exported():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(L, name), f"libick.so does not export {name} declared in include/ick.h"
-    assert _lib.lib().ick_abi_version() == _lib.ABI_VERSION == 6
+    assert _lib.lib().ick_abi_version() == _lib.ABI_VERSION == 7
     # every extern "C" entry of the sources is declared in the header (no undeclared ABI)
     import glob
     import re
@@ -309,3 +309,21 @@ def test_bench_roofline_denominators():
     assert b.mfma_peak("bf16") == pytest.approx(28.41 / t, rel=1e-3)
     assert b.mfma_peak("bf16") > b.mfma_peak("bf16x3") > b.mfma_peak("f32")
     assert b.mfma_peak("f32", 20.95) == pytest.approx(157.3, rel=1e-3)      # cfg5 split, same peak for pure fp32
+
+
+def test_one_cycle_schedule_equals_torch_onecyclelr():
+    """OptimizedKDTrainer's host-side schedule against torch.optim.lr_scheduler.OneCycleLR with the reference's settings
+    (train_student_kd_optimized.py:369-378; cycle_momentum left at torch's default True): learning rate and Adam's beta1."""
+    import torch
+    from torch.optim.lr_scheduler import OneCycleLR
+    from imagecaptioner_amd.train_student_kd_optimized import one_cycle
+    for total, max_lr in ((37, 3e-3), (20, 1e-3), (1000, 5e-4)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        o = torch.optim.AdamW([p], lr=1e-3)
+        s = OneCycleLR(o, max_lr=max_lr, total_steps=total, pct_start=0.1, anneal_strategy="cos", div_factor=10, final_div_factor=100)
+        for k in range(total):
+            lr, b1 = one_cycle(k, total, max_lr)
+            assert abs(lr - o.param_groups[0]["lr"]) < 1e-12 and abs(b1 - o.param_groups[0]["betas"][0]) < 1e-12, (total, k)
+            o.step()
+            if k < total - 1:
+                s.step()
