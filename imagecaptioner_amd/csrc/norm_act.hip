@@ -395,6 +395,9 @@ __global__ __launch_bounds__(NT) void bn_bwd_reduce_kernel(const T* __restrict__
   }
 }
 
+// (Round 3 tried folding the copies inside the apply kernel instead — every thread folding its own four channels — to save
+//  this launch: 29 launches x 5.7 us gone, but the apply kernel went from 17 to 34 us on average, 2 x 4 x copies dependent fp64
+//  loads in the prologue of every thread of a 2048-block grid: +0.33 ms per step net, reverted.)
 // BN backward pass 2a: fold the accumulator copies once — coef = {sum_g / M, sum_gx / M} as floats for the apply pass, and the
 // parameter gradients, which are the two reductions themselves: dgamma += sum(g * xhat), dbeta += sum(g).
 __global__ void bn_bwd_fold_kernel(const double* __restrict__ sum_g, const double* __restrict__ sum_gx, int copies, long stride,
@@ -414,9 +417,7 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
                                     const T* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ inv, const float* __restrict__ gamma,
                                     const float* __restrict__ coef, T* __restrict__ dx, T* __restrict__ gout,
-                                    long total4, int C4, int use_batch_stats, int hoist, float hi,
-                                    const double* __restrict__ sum_g, const double* __restrict__ sum_gx, int copies, long stride,
-                                    double invM, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                    long total4, int C4, int use_batch_stats, int hoist, float hi) {
   // hoist: the grid stride is a multiple of C4 (launcher), so a thread's 4 channels never change: per-channel terms once.
   // Otherwise (C/4 neither divides nor is a multiple of 256: MobileNetV2's 96, 144, 576 ...) they are re-read per element.
   const long i0 = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -426,23 +427,8 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ dy, const T* __restric
   float4 mu = make_float4(0, 0, 0, 0), mg = mu, mx = mu;
   if (use_batch_stats) {
     mu = reinterpret_cast<const float4*>(mean)[c];
-    if (sum_g) {
-      // hoisted channels (the launcher passes the sums only then): every thread folds the accumulator copies of ITS four
-      // channels itself — 2 x 4 x copies fp64 loads that hit in L2 — instead of a separate fold launch per BatchNorm
-      // (29 launches per step); the first C4 threads of the grid also own the parameter gradients
-      double sg[4], sx[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) { sg[j] = fold_copies(sum_g, 4 * c + j, copies, stride); sx[j] = fold_copies(sum_gx, 4 * c + j, copies, stride); }
-      mg = make_float4((float)(sg[0] * invM), (float)(sg[1] * invM), (float)(sg[2] * invM), (float)(sg[3] * invM));
-      mx = make_float4((float)(sx[0] * invM), (float)(sx[1] * invM), (float)(sx[2] * invM), (float)(sx[3] * invM));
-      if (dgamma && i0 < C4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { dgamma[4 * c + j] += (float)sx[j]; dbeta[4 * c + j] += (float)sg[j]; }
-      }
-    } else {
-      mg = reinterpret_cast<const float4*>(coef)[c];
-      mx = reinterpret_cast<const float4*>(coef)[C4 + c];
-    }
+    mg = reinterpret_cast<const float4*>(coef)[c];
+    mx = reinterpret_cast<const float4*>(coef)[C4 + c];
   }
   for (long i = i0; i < total4; i += (long)gridDim.x * blockDim.x) {
     if (!hoist) {
@@ -869,18 +855,15 @@ int bn_bwd_apply_impl(const T* dy, const T* y, const T* x, const float* mean, co
   ICK_REQUIRE(!use_batch_stats || (sum_g && sum_gx && coef_ws), "ick_bn_bwd_apply: batch statistics need the two sums and the 2*C workspace");
   const int C4 = C / 4;
   const int hoist = (C4 <= NT ? NT % C4 == 0 : C4 % NT == 0) ? 1 : 0;
+  if (use_batch_stats)
+    ICK_LAUNCH(bn_bwd_fold_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum_g, sum_gx, copies, (long)stride, 1.0 / (double)M,
+               coef_ws, dgamma, dbeta, C);
   const long total4 = M * C4;
   int grid = grid_for(total4);
   const int q = (hoist && C4 > NT) ? C4 / NT : 1;          // grid * NT must be a multiple of C4: a thread keeps its channels
   grid = (grid + q - 1) / q * q;
-  // hoisted channels + a grid that covers every channel group: the apply kernel folds the accumulator copies itself
-  const bool inline_fold = use_batch_stats && hoist && (long)grid * NT >= C4;
-  if (use_batch_stats && !inline_fold)
-    ICK_LAUNCH(bn_bwd_fold_kernel, dim3((C + NT - 1) / NT), dim3(NT), 0, ST, sum_g, sum_gx, copies, (long)stride, 1.0 / (double)M,
-               coef_ws, dgamma, dbeta, C);
   ICK_LAUNCH(bn_bwd_apply_kernel<T>, dim3(grid), dim3(NT), 0, ST, dy, y, x, mean, invstd, gamma, coef_ws, dx, g_out, total4, C4,
-             use_batch_stats, hoist, act == 2 ? 6.f : INFINITY, inline_fold ? sum_g : (const double*)nullptr, sum_gx, copies, (long)stride,
-             1.0 / (double)M, dgamma, dbeta);
+             use_batch_stats, hoist, act == 2 ? 6.f : INFINITY);
   return ick::launch_status("bn_bwd_apply");
 }
 
