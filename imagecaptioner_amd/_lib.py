@@ -22,7 +22,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libick.so")
 HEADER = os.path.join(os.path.dirname(HERE), "include", "ick.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 OP_NT, OP_NN, OP_TN, OP_CONV_FWD, OP_CONV_FWD_C4, OP_CONV_DGRAD, OP_CONV_WGRAD, OP_CONV_DGRAD_S2 = range(8)
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_TANH = range(4)
 ACT_POST_RESIDUAL = 16
@@ -44,7 +44,7 @@ class IckGemm(ctypes.Structure):
         ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32), ("Cout", ctypes.c_int32),
         ("R", ctypes.c_int32), ("S", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32),
         ("tile", ctypes.c_int32), ("stat_copies", ctypes.c_int32), ("stat_stride", ctypes.c_int64), ("col_scale", ctypes.c_void_p),
-        ("kchunk", ctypes.c_int32), ("io16", ctypes.c_int32),
+        ("kchunk", ctypes.c_int32), ("io16", ctypes.c_int32), ("a_absmax", ctypes.c_void_p),
     ]
 
 

@@ -439,6 +439,22 @@ void igemm_glds_kernel(const P p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) tot[i][j][r] = 0.f;
   int chain = 0;
+  // TERMS 4 with IckGemm.a_absmax: s = 2^(11 - e) for max |A| = m 2^e, m in [0.5, 1): max |A| s lies in [2^10, 2^11); a zero
+  // or non-finite maximum leaves A alone
+  bool a_scaled = false;
+  float a_sc = 1.f, a_inv = 1.f;
+  if constexpr (TERMS == 4) {
+    if (p.a_absmax) {
+      const float am = *p.a_absmax;                       // (uniform: every lane loads the same word)
+      if (am > 0.f && am < 3.0e38f) {
+        int e;
+        (void)frexpf(am, &e);
+        a_sc = ldexpf(1.f, 11 - e);
+        a_inv = ldexpf(1.f, e - 11);
+        a_scaled = true;
+      }
+    }
+  }
 
   constexpr bool IL = (ICK_EXP & 2) != 0 && TERMS == 0 && LW == 0;   // piecewise DMA schedule (knob 2)
   auto stamp = [&](int slot, bool on) {
@@ -591,6 +607,12 @@ void igemm_glds_kernel(const P p) {
         }
         using h8 = typename Half16<TERMS>::x8;
         h8 ah[TM], bh[TN], al[TM], bl[TN];
+        if constexpr (TERMS == 4) {
+          if (a_scaled) {            // IckGemm.a_absmax: A times the power of two that puts its maximum into fp16's best range (exact)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[cur][i] = av[cur][i] * a_sc;
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           ah[i] = __builtin_convertvector(av[cur][i], h8);
@@ -642,7 +664,7 @@ void igemm_glds_kernel(const P p) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int t = 0; t < TN; ++t) acc[i][t] += tot[i][t] * (1.f / 2048.f);
+      for (int t = 0; t < TN; ++t) acc[i][t] = (acc[i][t] + tot[i][t] * (1.f / 2048.f)) * a_inv;    // (a_inv = 1 without a_absmax)
   }
   if constexpr (IL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last k-tiles' zero-page pieces must land before the buffers become the C slab
   stamp(2, true);

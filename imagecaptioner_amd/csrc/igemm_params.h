@@ -23,6 +23,7 @@ struct P {  // kernel parameters (by value)
   int chunk_tiles;   // fold the MFMA accumulators into the master sum every chunk_tiles k-tiles (0 = never)
   int ep_vec;   // LDS-staged 16-byte epilogue allowed (set by the launcher from the alignment of C / residual)
   int c16, r16;   // native 16-bit kernels only (IckGemm.io16): C / the residual hold bf16 or fp16 elements (the operand type)
+  const float* a_absmax;   // TERMS 4 only: device pointer to max |A| (IckGemm.a_absmax); NULL = A is used as it is
 };
 
 // which fetch pattern each op uses for its A and B operands
@@ -137,6 +138,7 @@ inline int prepare(const IckGemm* d, int bk, P& p, int& nz, const char* who) {
   p.A = d->A; p.B = d->B; p.C = d->C; p.bias = d->bias; p.residual = d->residual;
   p.stat_sum = d->stat_sum; p.stat_sq = d->stat_sq;
   p.col_scale = d->col_scale;
+  p.a_absmax = d->a_absmax;
   p.c16 = d->io16 & 1; p.r16 = (d->io16 >> 1) & 1;
   p.stat_copies = d->stat_copies > 1 ? d->stat_copies : 1; p.stat_stride = d->stat_stride;
   ICK_REQUIRE(p.stat_copies == 1 || p.stat_stride >= d->N, "%s: stat_stride must be >= N", who);

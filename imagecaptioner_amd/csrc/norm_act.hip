@@ -714,6 +714,27 @@ __global__ void colsum_kernel(const float* __restrict__ x, float* __restrict__ o
   atomicAdd(out + n, (s0 + s1) + (s2 + s3));
 }
 
+// out[0] = max(out[0], max |x|): non-negative floats order like their bit patterns
+__global__ void absmax_kernel(const float* __restrict__ x, long n4, float* __restrict__ out) {
+  float m = 0.f;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  // ONE atomic per workgroup (first form: one per wave from ~800 workgroups = 3000 same-address atomics, 41 us per launch)
+  __shared__ float wmax[NT / 64];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float b = wmax[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) b = fmaxf(b, wmax[w]);
+    atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(b));
+  }
+}
+
 // dx = dy * (y > 0)
 __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ dx,
                                 long total4) {
@@ -1061,6 +1082,12 @@ int ick_colsum(const float* x, float* out, long M, int N, long ld, void* stream)
   long gy = (M + 15) / 16; if (gy > 512) gy = 512;       // ~16 rows per thread (measured: 64 rows per thread left the launch latency-bound at 15 us)
   ICK_LAUNCH(colsum_kernel, dim3((N + NT - 1) / NT, (int)gy), dim3(NT), 0, ST, x, out, M, N, ld);
   return ick::launch_status("colsum");
+}
+
+int ick_absmax_f32(const float* x, int64_t n, float* out, void* stream) {
+  ICK_REQUIRE(x && out && n > 0 && n % 4 == 0 && ick::aligned16(x), "ick_absmax_f32: bad arguments (n %% 4)");
+  ICK_LAUNCH(absmax_kernel, dim3(grid_for(n / 4, NT * 8, 512)), dim3(NT), 0, ST, x, (long)(n / 4), out);
+  return ick::launch_status("absmax_f32");
 }
 
 int ick_relu_bwd(const float* dy, const float* y, float* dx, long n, void* stream) {

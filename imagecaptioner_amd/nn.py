@@ -557,6 +557,8 @@ class ResNetTrunkFn(Function):
             d = _c(dy).view(recs[-1]["out"].shape)
         if ctx.dt16 is not None:
             d = ops.cast16(d, ctx.dt16)                              # gradients travel through the trunk in the storage type
+        if ops.gemm_precision() == "f32x3":
+            ops.begin_absmax_arena(64, d.device)     # one zero fill for the absmax slots of this backward's data gradients
         state = dict(blocks=blocks, first=first, recs=recs, d=d, next=len(blocks) - 1, stem=ctx.stem,
                      sums=_Arena(2 * ops.BN_BWD_COPIES * _bn_channels(blocks[first:]), torch.float64, d.device))
         if _TRUNK_DEFER["on"]:

@@ -127,11 +127,12 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
              accumulate: bool = False, stat_sum: Optional[int] = None, stat_sq: Optional[int] = None,
              conv: Optional[Tuple[int, ...]] = None, tile: int = 0, stat_copies: int = 1, stat_stride: int = 0,
              col_scale: Optional[int] = None, kchunk: int = 0, h16: Optional[torch.dtype] = None, io16: int = 0,
-             default_tile: int = 0, x3: bool = False) -> None:
+             default_tile: int = 0, x3: bool = False, a_absmax: Optional[int] = None) -> None:
     """h16 = torch.bfloat16 / torch.float16: A and B hold that type in HBM (ick_gemm_h16); io16 bit 0 / 1: so do C / the
     residual.  x3: the call site states that both operands are FORWARD quantities (activations, weights: magnitudes inside
     fp16's normal range) — only such launches take the three-fp16-product kernel under precision "f32x3"; gradients, whose
-    magnitudes can sit below fp16's 6e-5, always take the exact-fp32 kernel there."""
+    magnitudes can sit below fp16's 6e-5, take the exact-fp32 kernel there UNLESS the caller also passes a_absmax: a device
+    pointer to max |A| (ops.absmax), from which the kernel takes the power-of-two scale that puts A into fp16's range (exact)."""
     d = IckGemm()
     d.A, d.B, d.C = A, B, C
     d.bias, d.residual, d.stat_sum, d.stat_sq = bias, residual, stat_sum, stat_sq
@@ -154,6 +155,7 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
     terms = _PRECISIONS[_PREC[0]]
     if terms == 4 and not (x3 and op in (OP_NT, OP_CONV_FWD)):
         terms = 0
+    d.a_absmax = a_absmax if terms == 4 else None
     d.io16 = io16        # (fp32 operands: only the bf16 / fp16 LDS-DMA variants can write a 16-bit C; the others refuse)
     if terms == 4:
         d.tile = tile or _FORCE_TILE[0] or _TUNED_X3.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
@@ -474,14 +476,49 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride
                      residual=_ptr(residual), ldr=Cin, splitk=sk, default_tile=4 if K >= 4096 else 2,
                      conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad))
             return dx
+        am = None
+        if _PREC[0] == "f32x3" and h16 is None and _X3_DGRAD[0] and dy.numel() % 4 == 0:
+            # the gradient's magnitude is anything (1e-6 and below in this trunk): its maximum, taken on the device, gives the
+            # kernel the exact power-of-two scale that puts it into fp16's range — the three-product kernel then serves data
+            # gradients as it serves forward activations (IckGemm.a_absmax)
+            am = absmax(dy, _absmax_slot(dy.device))
         gemm_raw(OP_CONV_FWD, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, K, K, Cin,
                  residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
-                 conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad), **io)
+                 conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad), x3=am is not None, a_absmax=_ptr(am), **io)
         return dx
     gemm_raw(OP_CONV_DGRAD, dy.data_ptr(), w.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, 0, 0, Cin,
              residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
              conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), **io)
     return dx
+
+
+def absmax(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[0] = max(out[0], max |x|) on the device (out: one non-negative float, 0 for a fresh maximum); x.numel() % 4 == 0."""
+    check(_lib.lib().ick_absmax_f32(_chk(x, "x").data_ptr(), x.numel(), out.data_ptr(), _st()), "ick_absmax_f32")
+    return out
+
+
+_ABSMAX_ARENA = {"buf": None, "next": 0}
+
+
+def begin_absmax_arena(n: int = 64, device="cuda") -> None:
+    """one zero fill for the next n absmax slots (a backward pass opens this; without it every slot is its own torch.zeros)"""
+    _ABSMAX_ARENA["buf"], _ABSMAX_ARENA["next"] = torch.zeros(n, dtype=_F32, device=device), 0
+
+
+def end_absmax_arena() -> None:
+    _ABSMAX_ARENA["buf"], _ABSMAX_ARENA["next"] = None, 0
+
+
+def _absmax_slot(device) -> torch.Tensor:
+    a = _ABSMAX_ARENA
+    if a["buf"] is not None and a["next"] < a["buf"].numel() and a["buf"].device == device:
+        a["next"] += 1
+        return a["buf"][a["next"] - 1:a["next"]]
+    return torch.zeros(1, dtype=_F32, device=device)
+
+
+_X3_DGRAD = [os.environ.get("ICK_X3_DGRAD", "1") != "0"]     # precision "f32x3": stride-1 data gradients on the three-product kernel too
 
 
 def conv_weight_dgrad_layout(w: torch.Tensor) -> torch.Tensor:

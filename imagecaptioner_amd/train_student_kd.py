@@ -107,7 +107,8 @@ class KDTrainer:
         under precision "f32" and "f32x3" otherwise: fp32-GRADE Linears from three fp16 MFMAs per product (igemm_glds_impl.h
         TERMS 4; error against float64 equal to the exact kernel's, tests/test_gemm_gpu.py::test_f32x3_is_fp32_grade), 2x the
         exact kernel — in the mixed-precision regimes the fp32 teacher is otherwise more than half of the step.
-        precision "f32x3": every forward Linear / convolution of the student that way too, every gradient launch exact fp32."""
+        precision "f32x3": every forward Linear / convolution of the student that way too, and the trunk's stride-1 data gradients
+        with the power-of-two scale of their device-side absmax (IckGemm.a_absmax); weight gradients on the exact fp32 MFMA."""
         if teacher_precision is None:
             teacher_precision = "f32" if precision == "f32" else "f32x3"
         self.precision, self.teacher_precision = precision, teacher_precision

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define ICK_ABI_VERSION 7
+#define ICK_ABI_VERSION 8
 
 const char* ick_last_error(void);
 int ick_abi_version(void);
@@ -75,6 +75,7 @@ typedef struct IckGemm {
   const float* col_scale;                       /* [N] or NULL: C = act(col_scale[n] * alpha*sum + bias[n] ...) — eval-mode BatchNorm folded into the conv epilogue (scale = gamma/sqrt(var+eps), bias = shift); needs N %% 4, ldc %% 4, no split-K */
   int32_t kchunk;                               /* fp32 kernels: k elements one MFMA accumulator chain sums before it is folded into a master accumulator (bounds the rounding error of long-K products the way a K-blocked CPU GEMM does); 0 = library default (64), < 0 = one chain over all of K */
   int32_t io16;                                 /* ick_gemm_h16 only (0 elsewhere): bit 0 = C holds 16-bit elements of the operand type (also what `accumulate` reads), bit 1 = the residual does; both need the vector epilogue (N %% 4, ldc %% 4, ldr %% 4, no split-K) */
+  const float* a_absmax;                        /* ick_gemm_bf16(terms = 4) only (NULL elsewhere): device pointer to max |A| (ick_absmax_f32).  The kernel multiplies A by the power of two that brings that maximum to [2^10, 2^11) before the fp16 split and divides the result by it: three-product GEMMs for operands of ANY magnitude, e.g. the data gradients of the trunk (1e-6 and below), with full 2^-22 relative precision for elements down to 3e-8 of the maximum */
 } IckGemm;
 
 int ick_gemm_f32(const IckGemm* desc, void* stream);
@@ -95,6 +96,9 @@ int ick_gemm_f32(const IckGemm* desc, void* stream);
  * convolution of the 16-bit training regime reads fp32 images and writes 16-bit activations this way.
  * Convolutions whose channel count is not a multiple of 32 run on the exact-fp32 kernel. */
 int ick_gemm_bf16(const IckGemm* desc, int terms, void* stream);
+/* out[0] = max(out[0], max_i |x[i]|) — out must hold a non-negative float on entry (0 for a fresh maximum); n %% 4 == 0.  The
+ * producer of IckGemm.a_absmax. */
+int ick_absmax_f32(const float* x, int64_t n, float* out, void* stream);
 /* NATIVE 16-bit operands: A and B hold bf16 (fp16 = 0) or fp16 (fp16 = 1) elements in HBM and in LDS — the storage the
  * reference's autocast keeps its activations and weight copies in (train_student_kd.py:271); fp32 accumulation, fp32
  * bias / statistics / epilogue arithmetic; C and the residual are fp32 or (IckGemm.io16) 16-bit.  Every op of the family;

@@ -20,7 +20,7 @@ def test_header_symbols_are_exported():
     L = ctypes.CDLL(_lib.LIB_PATH)
     for name in protos:
         assert hasattr(L, name), f"libick.so does not export {name} declared in include/ick.h"
-    assert _lib.lib().ick_abi_version() == _lib.ABI_VERSION == 7
+    assert _lib.lib().ick_abi_version() == _lib.ABI_VERSION == 8
     # every extern "C" entry of the sources is declared in the header (no undeclared ABI)
     import glob
     import re

@@ -319,3 +319,56 @@ def test_f32x3_is_fp32_grade(M, N, K, act):
         errs[prec] = ((y[:512].double().cpu() - ref).norm() / ref.norm()).item()
     print(M, N, K, errs)
     assert errs["f32x3"] <= 1.25 * errs["f32"] and errs["f32x3"] < 5e-7, errs
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-7, 3e-12, 4e4])
+def test_f32x3_with_absmax_scale_is_fp32_grade_for_any_magnitude(scale):
+    """IckGemm.a_absmax (round 3): the three-fp16-product kernel takes max |A| from device memory and multiplies A by the power
+    of two that puts it into fp16's range — so data gradients (1e-6 and far below) get fp32-grade products too.  A stride-1
+    3x3 data gradient (forward convolution over dY with rotated weights) at layer3's geometry with dY scaled over sixteen
+    decades, elements spread over four more.  Bound: 4e-7 relative L2 against float64 at EVERY scale — the level of a K-blocked
+    CPU fp32 convolution on this K = 2304 contraction (the exact-fp32 kernel, which folds its accumulator chain every 64 k, reaches
+    1.1e-7 here; the three-product kernel's chain of 144 accumulations 2.9e-7; an unfolded fp32 MFMA chain 1.8e-6) — and
+    the SAME error at every scale; without the scale the same launch loses every low part at 1e-7 (asserted too)."""
+    from imagecaptioner_amd import ops as o
+    g = torch.Generator().manual_seed(11)
+    Nb, H, C = 8, 14, 256
+    dy = torch.randn(Nb, H, H, C, generator=g) * torch.logspace(-4, 0, C) * scale
+    w = torch.randn(C, 3, 3, C, generator=g) * 0.03
+    ref = torch.nn.grad.conv2d_input((Nb, C, H, H), w.double().permute(0, 3, 1, 2), dy.double().permute(0, 3, 1, 2), padding=1)
+    errs = {}
+    for prec in ("f32", "f32x3"):
+        with o.precision(prec):
+            dx = o.conv_dgrad(dy.cuda(), w.cuda(), (H, H), 1, 1)
+        errs[prec] = ((dx.double().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item()
+    o._X3_DGRAD[0] = False
+    try:
+        with o.precision("f32x3"):
+            dx = o.conv_dgrad(dy.cuda(), w.cuda(), (H, H), 1, 1)      # exact kernel (gradients never take x3 unscaled)
+        errs["f32x3, no scale (exact kernel)"] = ((dx.double().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item()
+    finally:
+        o._X3_DGRAD[0] = True
+    print(scale, errs)
+    assert errs["f32x3"] < 4e-7 and errs["f32x3"] <= 3.0 * errs["f32"], errs
+    # the raw three-product kernel WITHOUT the scale on the same operands: fine at O(1), useless at 1e-7
+    wt = o.conv_weight_dgrad_layout(w.cuda())
+    dxr = torch.empty(Nb, H, H, C, device="cuda")
+    with o.precision("f32x3"):
+        o.gemm_raw(o.OP_CONV_FWD, dy.cuda().data_ptr(), wt.data_ptr(), dxr.data_ptr(), Nb * H * H, C, 9 * C, 9 * C, 9 * C, C,
+                   conv=(Nb, H, H, C, H, H, C, 3, 3, 1, 1), x3=True)
+    raw = ((dxr.double().cpu().permute(0, 3, 1, 2) - ref).norm() / ref.norm()).item()
+    if scale == 1e-7:
+        assert raw > 50 * errs["f32x3"], (raw, errs)
+
+
+def test_absmax_kernel():
+    from imagecaptioner_amd import ops as o
+    x = torch.randn(1 << 20) * 1e-5
+    x[123457] = -3.25e-2
+    out = torch.zeros(1, device="cuda")
+    o.absmax(x.cuda(), out)
+    assert out.item() == float(torch.tensor(3.25e-2, dtype=torch.float32))          # exact: a maximum, not a sum
+    o.absmax(torch.full((8,), 7.0).cuda(), out)            # accumulates: max with what is there
+    assert out.item() == 7.0
+    o.absmax(torch.zeros(8).cuda(), out)
+    assert out.item() == 7.0
