@@ -937,10 +937,11 @@ int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
     if (d->op == ICK_OP_TN) return dispatch_tile<ICK_OP_TN, TERMS>(p, nz, st, d->tile);               // x-contiguous operands (X16)
     if (d->op == ICK_OP_CONV_WGRAD) return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS>(p, nz, st, d->tile);
     return ick::fail(-1, "igemm (native 16-bit, LDS-DMA): NT, CONV_FWD, TN and CONV_WGRAD only, got op %d", d->op);
-  } else if constexpr (TERMS == 4) {   // the frozen teacher's forward products only
+  } else if constexpr (TERMS == 4) {   // forward products, data gradients run as forward convolutions, 1x1 weight gradients (TN)
     if (d->op == ICK_OP_NT) return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
     if (d->op == ICK_OP_CONV_FWD) return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
-    return ick::fail(-1, "igemm (f32x3, LDS-DMA): NT and CONV_FWD only, got op %d", d->op);
+    if (d->op == ICK_OP_TN) return dispatch_tile<ICK_OP_TN, TERMS>(p, nz, st, d->tile);
+    return ick::fail(-1, "igemm (f32x3, LDS-DMA): NT, CONV_FWD and TN only, got op %d", d->op);
   } else
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);

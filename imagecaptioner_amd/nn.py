@@ -582,8 +582,11 @@ def trunk_backward_stage(state: dict, stop: int) -> None:
     for i in range(state["next"], stop - 1, -1):
         state["d"] = bottleneck_backward(blocks[i], recs[i - first], state["d"], i > first or stem is not None, state["sums"])
         recs[i - first] = None                                       # free this block's activations
+        ops._ABSMAX_ARENA["cache"].clear()                           # (a convolution's dgrad / wgrad pair shares its absmax pass; no longer)
     _join_wgrad_stream()
     state["next"] = stop - 1
+    if state["next"] < first:
+        ops.end_absmax_arena()                                       # (drops the references the absmax cache holds on gradient tensors)
     if stem is not None and state["next"] < first:                   # CNNEncoder(fine_tune=False): max-pool, bn1, conv1 adjoints
         bn, conv = stem["bn"], stem["conv"]
         d = ops.maxpool3x3s2_bwd(stem["ys"], state["d"])

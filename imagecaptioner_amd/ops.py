@@ -153,12 +153,12 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
         check(_lib.lib().ick_gemm_h16(ctypes.byref(d), int(h16 == torch.float16), _st()), "ick_gemm_h16")
         return
     terms = _PRECISIONS[_PREC[0]]
-    if terms == 4 and not (x3 and op in (OP_NT, OP_CONV_FWD)):
+    if terms == 4 and not (x3 and op in (OP_NT, OP_CONV_FWD, OP_TN)):
         terms = 0
     d.a_absmax = a_absmax if terms == 4 else None
     d.io16 = io16        # (fp32 operands: only the bf16 / fp16 LDS-DMA variants can write a 16-bit C; the others refuse)
     if terms == 4:
-        d.tile = tile or _FORCE_TILE[0] or _TUNED_X3.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", 0)
+        d.tile = tile or _FORCE_TILE[0] or _TUNED_X3.get(f"{op}:{M}:{N}:{K}:{batch[0] * batch[1]}:{splitk}", default_tile)
         check(_lib.lib().ick_gemm_bf16(ctypes.byref(d), terms, _st()), "ick_gemm_bf16")
         return
     if terms:
@@ -481,7 +481,7 @@ def conv_dgrad(dy: torch.Tensor, w: torch.Tensor, in_hw: Tuple[int, int], stride
             # the gradient's magnitude is anything (1e-6 and below in this trunk): its maximum, taken on the device, gives the
             # kernel the exact power-of-two scale that puts it into fp16's range — the three-product kernel then serves data
             # gradients as it serves forward activations (IckGemm.a_absmax)
-            am = absmax(dy, _absmax_slot(dy.device))
+            am = _grad_absmax(dy)
         gemm_raw(OP_CONV_FWD, dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), Nb * H * W, Cin, K, K, K, Cin,
                  residual=_ptr(residual), ldr=Cin, accumulate=accumulate,
                  conv=(Nb, Ho, Wo, Cout, H, W, Cin, R, S, 1, R - 1 - pad), x3=am is not None, a_absmax=_ptr(am), **io)
@@ -498,16 +498,29 @@ def absmax(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     return out
 
 
-_ABSMAX_ARENA = {"buf": None, "next": 0}
+_ABSMAX_ARENA = {"buf": None, "next": 0, "cache": {}}
 
 
 def begin_absmax_arena(n: int = 64, device="cuda") -> None:
     """one zero fill for the next n absmax slots (a backward pass opens this; without it every slot is its own torch.zeros)"""
-    _ABSMAX_ARENA["buf"], _ABSMAX_ARENA["next"] = torch.zeros(n, dtype=_F32, device=device), 0
+    _ABSMAX_ARENA["buf"], _ABSMAX_ARENA["next"], _ABSMAX_ARENA["cache"] = torch.zeros(n, dtype=_F32, device=device), 0, {}
 
 
 def end_absmax_arena() -> None:
-    _ABSMAX_ARENA["buf"], _ABSMAX_ARENA["next"] = None, 0
+    _ABSMAX_ARENA["buf"], _ABSMAX_ARENA["next"], _ABSMAX_ARENA["cache"] = None, 0, {}
+
+
+def _grad_absmax(dy: torch.Tensor) -> torch.Tensor:
+    """max |dy| on the device; inside an arena (one backward pass) the data gradient and the weight gradient of a convolution,
+    which read the same dy, share one pass"""
+    a = _ABSMAX_ARENA
+    key = (dy.data_ptr(), dy.numel(), dy._version)
+    if a["buf"] is not None and key in a["cache"]:
+        return a["cache"][key][0]
+    am = absmax(dy, _absmax_slot(dy.device))
+    if a["buf"] is not None:
+        a["cache"][key] = (am, dy)              # (dy kept alive: its address must not be handed to another tensor meanwhile)
+    return am
 
 
 def _absmax_slot(device) -> torch.Tensor:
@@ -551,8 +564,13 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int,
         # profiles/r03_wgrad_1x1_as_tn.log: 1024x256x12544 68.7 us against 84; 128x512x50176 74 against 106).  ~800 pixels per
         # split (8 <= splits <= 48); the tile comes from the tuned table (128x64 otherwise)
         sk = splitk if splitk > 0 else (max(8, min(48, K // 784)) if K >= 3136 else max(1, K // 392))
+        x3kw = {}
+        if _PREC[0] == "f32x3" and _X3_DGRAD[0] and dy.numel() % 4 == 0 and sk > 1:
+            # three-product kernel for the weight gradient too: A = dY carries the scale of its absmax, B = X is a forward
+            # activation; the split keeps every accumulator chain to ~800 pixels
+            x3kw = dict(x3=True, a_absmax=_grad_absmax(dy).data_ptr())
         if sk > 1:
-            gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, Cin, K, Cout, Cin, Cin, splitk=sk, default_tile=3)
+            gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, Cin, K, Cout, Cin, Cin, splitk=sk, default_tile=3, **x3kw)
         else:
             gemm_raw(OP_TN, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, Cin, K, Cout, Cin, Cin, accumulate=True, default_tile=3)
         return

@@ -372,3 +372,22 @@ def test_absmax_kernel():
     assert out.item() == 7.0
     o.absmax(torch.zeros(8).cuda(), out)
     assert out.item() == 7.0
+
+
+def test_f32x3_weight_gradient_as_tn_with_absmax_scale():
+    """1x1 / stride-1 weight gradient under precision "f32x3": the TN product dW = dY^T X on the three-product kernel, dY scaled
+    by its device-side absmax (gradient magnitudes 1e-7 here), split-K with fp32 atomics: against float64, beside the exact path."""
+    from imagecaptioner_amd import ops as o
+    g = torch.Generator().manual_seed(3)
+    Nb, H, Cin, Cout = 16, 14, 1024, 256
+    x = torch.randn(Nb, H, H, Cin, generator=g)
+    dy = torch.randn(Nb, H, H, Cout, generator=g) * torch.logspace(-3, 0, Cout) * 1e-7
+    ref = dy.double().view(-1, Cout).T @ x.double().view(-1, Cin)
+    errs = {}
+    for prec in ("f32", "f32x3"):
+        dw = torch.zeros(Cout, 1, 1, Cin, device="cuda")
+        with o.precision(prec):
+            o.conv_wgrad(dy.cuda(), x.cuda(), dw, 1, 0)
+        errs[prec] = ((dw.view(Cout, Cin).double().cpu() - ref).norm() / ref.norm()).item()
+    print(errs)
+    assert errs["f32x3"] < 4e-7 and errs["f32x3"] <= 3.0 * errs["f32"], errs
