@@ -39,7 +39,7 @@ def mfma_peak(precision: str, gflop_student: float = GFLOP_STUDENT, teacher_prec
     ps = {"f32": PEAK_F32_MFMA_TF, "bf16": PEAK_BF16_MFMA_TF, "fp16": PEAK_BF16_MFMA_TF, "bf16x3": PEAK_BF16_MFMA_TF / 3, "f32x3": None}[precision]
     pt = PEAK_F32_MFMA_TF if teacher_precision == "f32" else PEAK_BF16_MFMA_TF / 3     # "f32x3": three fp16 MFMAs per product
     if precision == "f32x3":      # forward products (8.73 GFLOP/image), the stride-1 data gradients of layer3 / layer4 (~4.0)
-        x3 = 8.73 + 4.0 + 2.0     # and their 1x1 weight gradients (~2.0) as three fp16 MFMAs, every other gradient launch on the exact fp32 MFMA
+        x3 = 8.73 + 4.0 + 4.5     # and their weight gradients (~4.5) as three fp16 MFMAs; stride-2 data gradients + the head's backward exact fp32
         return (GFLOP_TEACHER + gflop_student) / (GFLOP_TEACHER / pt + x3 / (PEAK_BF16_MFMA_TF / 3) + (gflop_student - x3) / PEAK_F32_MFMA_TF)
     return (GFLOP_TEACHER + gflop_student) / (GFLOP_TEACHER / pt + gflop_student / ps)
 BATCH = 64
@@ -402,7 +402,7 @@ def main():
         dtype = {"f32": "f32", "bf16": "bf16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights) + f32 teacher",
                  "fp16": "fp16 student (16-bit activation + weight-shadow storage in the trunk, fp32 accumulate, fp32 master weights, device GradScaler) + f32 teacher",
                  "bf16x3": "split-bf16x3 student + f32 teacher",
-                 "f32x3": "f32-grade: forward Linears / convolutions + stride-1 data gradients + 1x1 weight gradients as three fp16 MFMAs per product, the rest exact fp32 MFMA"}[args.precision]
+                 "f32x3": "f32-grade: forward Linears / convolutions + the trunk's stride-1 data gradients and weight gradients as three fp16 MFMAs per product, the rest exact fp32 MFMA"}[args.precision]
         out = {
             "metric": "images/sec KD train step (teacher+student fwd + KD loss + bwd)", "value": round(ips, 2),
             "unit": "images/s", "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup,
@@ -433,8 +433,8 @@ def main():
                         ("fp16", "fp16", "f32x3", f"fp16 {S16}, device GradScaler 2^16; {X3} — KDTrainer's default teacher in this regime"),
                         ("bf16", "bf16", "f32x3", f"bf16 {S16}; {X3}"),
                         ("fp16_exact_fp32_teacher", "fp16", "f32", f"fp16 {S16}, device GradScaler 2^16; teacher on the exact fp32 MFMA (rounds 1-2's fp16 line)"),
-                        ("f32x3", "f32x3", "f32x3", "fp32-grade step: every FORWARD Linear / convolution of teacher and student and the trunk's stride-1 data gradients + 1x1 weight gradients (dY scaled by "
-                                                    "its device-side absmax) as three fp16 MFMAs per product, the 3x3 / strided gradients exact fp32 MFMA "
+                        ("f32x3", "f32x3", "f32x3", "fp32-grade step: every FORWARD Linear / convolution of teacher and student and the trunk's stride-1 data gradients + weight gradients (dY scaled by "
+                                                    "its device-side absmax) as three fp16 MFMAs per product, stride-2 data gradients and the head's backward exact fp32 MFMA "
                                                     "(tests/test_kd_step_b16_gpu.py[f32x3]: same fp64 yardstick as the exact path)"),
                         ("f32_teacher_f32x3", "f32", "f32x3", f"student exact fp32 MFMA; {X3}")):
                     ips2, dt2, dev2, loss2 = run_kd(args, prec2, dev, rank, world, log, teacher_precision=tprec2)

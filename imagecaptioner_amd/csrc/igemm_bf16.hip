@@ -642,7 +642,8 @@ extern "C" int ick_gemm_bf16(const IckGemm* d, int terms, void* stream) {
   ICK_REQUIRE(d != nullptr, "ick_gemm_bf16: null descriptor");
   ICK_REQUIRE(d->io16 == 0 || terms < 3, "ick_gemm_bf16: a 16-bit C / residual needs terms 1 (bf16) or 2 (fp16)");
   if (terms == 4) {   // fp32-grade results: the three-product kernel where it exists (k-contiguous forward products), exact fp32 MFMA elsewhere
-    const bool fwd = (d->op == ICK_OP_NT || d->op == ICK_OP_CONV_FWD || d->op == ICK_OP_TN) && !(d->tile & 256) && glds_eligible(d);
+    const bool fwd = (d->op == ICK_OP_NT || d->op == ICK_OP_CONV_FWD || d->op == ICK_OP_TN || d->op == ICK_OP_CONV_WGRAD) && !(d->tile & 256) &&
+                     glds_eligible(d);
     if (!fwd) return ick_gemm_f32(d, stream);
     P p4; int nz4 = 1;
     if (int rc = prepare(d, BK, p4, nz4, "ick_gemm_bf16")) return rc;

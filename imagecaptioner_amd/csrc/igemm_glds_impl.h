@@ -941,7 +941,8 @@ int ICK_GLDS_ENTRY(const IckGemm* d, const P& p, int nz, hipStream_t st) {
     if (d->op == ICK_OP_NT) return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);
     if (d->op == ICK_OP_CONV_FWD) return dispatch_tile<ICK_OP_CONV_FWD, TERMS>(p, nz, st, d->tile);
     if (d->op == ICK_OP_TN) return dispatch_tile<ICK_OP_TN, TERMS>(p, nz, st, d->tile);
-    return ick::fail(-1, "igemm (f32x3, LDS-DMA): NT, CONV_FWD and TN only, got op %d", d->op);
+    if (d->op == ICK_OP_CONV_WGRAD) return dispatch_tile<ICK_OP_CONV_WGRAD, TERMS>(p, nz, st, d->tile);   // (gather = the DMA's source addressing: shared)
+    return ick::fail(-1, "igemm (f32x3, LDS-DMA): NT, CONV_FWD, TN and CONV_WGRAD only, got op %d", d->op);
   } else
   switch (d->op) {
     case ICK_OP_NT: return dispatch_tile<ICK_OP_NT, TERMS>(p, nz, st, d->tile);

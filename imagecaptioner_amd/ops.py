@@ -153,7 +153,7 @@ def gemm_raw(op: int, A: int, B: int, C: int, M: int, N: int, K: int, lda: int, 
         check(_lib.lib().ick_gemm_h16(ctypes.byref(d), int(h16 == torch.float16), _st()), "ick_gemm_h16")
         return
     terms = _PRECISIONS[_PREC[0]]
-    if terms == 4 and not (x3 and op in (OP_NT, OP_CONV_FWD, OP_TN)):
+    if terms == 4 and not (x3 and op in (OP_NT, OP_CONV_FWD, OP_TN, OP_CONV_WGRAD)):
         terms = 0
     d.a_absmax = a_absmax if terms == 4 else None
     d.io16 = io16        # (fp32 operands: only the bf16 / fp16 LDS-DMA variants can write a 16-bit C; the others refuse)
@@ -584,6 +584,8 @@ def conv_wgrad(dy: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, stride: int,
         tiles = ((Cout + 127) // 128) * ((N + 127) // 128)
         splitk = max(1, min(64, 768 // max(tiles, 1), K // 128))
     if splitk > 1:
+        if not io and _PREC[0] == "f32x3" and _X3_DGRAD[0] and dy.numel() % 4 == 0 and os.environ.get("ICK_X3_WGRAD3", "1") != "0":
+            io = dict(x3=True, a_absmax=_grad_absmax(dy).data_ptr())     # 3x3 / strided weight gradients on the three-product kernel too
         gemm_raw(OP_CONV_WGRAD, dy.data_ptr(), x.data_ptr(), dw.data_ptr(), Cout, N, K, Cout, 0, N, splitk=splitk,
                  conv=(Nb, H, W, Cin, Ho, Wo, Cout, R, S, stride, pad), **io)
     else:

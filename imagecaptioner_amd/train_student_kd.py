@@ -108,8 +108,8 @@ class KDTrainer:
         TERMS 4; error against float64 equal to the exact kernel's, tests/test_gemm_gpu.py::test_f32x3_is_fp32_grade), 2x the
         exact kernel — in the mixed-precision regimes the fp32 teacher is otherwise more than half of the step.
         precision "f32x3": every forward Linear / convolution of the student that way too, and the trunk's stride-1 data gradients
-        and 1x1 weight gradients with the power-of-two scale of dY's device-side absmax (IckGemm.a_absmax); 3x3 / strided weight
-        gradients, stride-2 data gradients and the head's backward on the exact fp32 MFMA."""
+        and weight gradients with the power-of-two scale of dY's device-side absmax (IckGemm.a_absmax); stride-2 data gradients
+        and the head's backward on the exact fp32 MFMA."""
         if teacher_precision is None:
             teacher_precision = "f32" if precision == "f32" else "f32x3"
         self.precision, self.teacher_precision = precision, teacher_precision

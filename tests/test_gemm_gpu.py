@@ -391,3 +391,24 @@ def test_f32x3_weight_gradient_as_tn_with_absmax_scale():
         errs[prec] = ((dw.view(Cout, Cin).double().cpu() - ref).norm() / ref.norm()).item()
     print(errs)
     assert errs["f32x3"] < 4e-7 and errs["f32x3"] <= 3.0 * errs["f32"], errs
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_f32x3_3x3_weight_gradient_with_absmax_scale(stride):
+    """3x3 weight gradient (CONV_WGRAD gather, stride 1 and 2) under precision "f32x3": the three-product kernel with dY scaled by
+    its device-side absmax (magnitudes 1e-7), split-K, against float64 beside the exact path."""
+    from imagecaptioner_amd import ops as o
+    g = torch.Generator().manual_seed(5 + stride)
+    Nb, H, Cin, Cout = 16, 14, 256, 256
+    Ho = (H + 2 - 3) // stride + 1
+    x = torch.randn(Nb, H, H, Cin, generator=g)
+    dy = torch.randn(Nb, Ho, Ho, Cout, generator=g) * torch.logspace(-3, 0, Cout) * 1e-7
+    ref = torch.nn.grad.conv2d_weight(x.double().permute(0, 3, 1, 2), (Cout, Cin, 3, 3), dy.double().permute(0, 3, 1, 2), stride=stride, padding=1)
+    errs = {}
+    for prec in ("f32", "f32x3"):
+        dw = torch.zeros(Cout, 3, 3, Cin, device="cuda")
+        with o.precision(prec):
+            o.conv_wgrad(dy.cuda(), x.cuda(), dw, stride, 1)
+        errs[prec] = ((dw.permute(0, 3, 1, 2).double().cpu() - ref).norm() / ref.norm()).item()
+    print(stride, errs)
+    assert errs["f32x3"] < 4e-7 and errs["f32x3"] <= 3.0 * errs["f32"], errs
