@@ -411,6 +411,12 @@ def test_staged_step_on_16bit_storage_equals_single_graph_step():
     test_staged_data_parallel_step_under_an_rccl_group_equals_single_graph_step(True, precision="fp16")
 
 
+def test_staged_step_under_f32x3_equals_single_graph_step():
+    """The same rehearsal with the forward products and the trunk's gradients on the three-product kernel (precision "f32x3"): the
+    absmax slots of the data / weight gradients are opened in stage 0's graph and used by the deferred trunk stages."""
+    test_staged_data_parallel_step_under_an_rccl_group_equals_single_graph_step(True, precision="f32x3")
+
+
 @pytest.mark.parametrize("use_graph", [False, True])
 def test_staged_step_bucket_hook_doubles_every_gradient_exactly_once(use_graph):
     """at world 1 the bucket all-reduce is the identity, so the rehearsal above cannot see a bucket that is
